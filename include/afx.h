@@ -1,0 +1,181 @@
+/* afx.h — C-ABI of the MI355X-native angiography-NeRF hot path ("afx").
+ *
+ * The upstream reference (kirstenmaas/nerf-for-angiography) has no FFI/plugin
+ * boundary: its hot path is Python calling torch.  The boundary this library
+ * replaces is therefore the set of Python functions cited on each entry point
+ * below (file:line in the upstream tree).  Everything here is plain C: raw
+ * device pointers, sizes and a hipStream_t passed as void*.  No torch types.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative afx_status otherwise;
+ *     afx_last_error() gives a thread-local message.  Nothing throws or exits.
+ *   - the CALLER owns every buffer (parameters, gradients, outputs, prepared
+ *     weights, workspace).  The library allocates nothing on the device and
+ *     holds only immutable descriptors => calls are hipGraph-capturable.
+ *   - all calls are asynchronous on the stream passed in; no hidden syncs.
+ *   - results are deterministic: no floating-point atomics anywhere.
+ */
+#ifndef AFX_H
+#define AFX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct afx_ctx afx_ctx;
+
+enum afx_status {
+  AFX_OK = 0,
+  AFX_E_INVALID = -1,      /* bad argument / unsupported configuration */
+  AFX_E_WORKSPACE = -2,    /* workspace or prepared-weights buffer too small */
+  AFX_E_HIP = -3           /* a HIP runtime call failed (message has the code) */
+};
+
+/* Positional encodings of CPPN.pos_enc (model/CPPN.py:207-234). */
+enum { AFX_ENC_NONE = 0, AFX_ENC_BARF = 1, AFX_ENC_FOURIER = 2 };
+
+/* Arithmetic of the MLP contractions.
+ *   F32    : v_mfma_f32_32x32x2_f32, exact fp32 (strict parity mode)
+ *   BF16X3 : split-bf16 (hi+lo) operands, 3 bf16 MFMAs per product, fp32
+ *            accumulate: fp32-grade accuracy at 1/3 of the bf16 rate
+ *   BF16   : bf16 operands, fp32 accumulate (first layer always split)     */
+enum { AFX_PREC_F32 = 0, AFX_PREC_BF16X3 = 1, AFX_PREC_BF16 = 2 };
+
+/* CPPN(model_definition) — model/CPPN.py:10-139.  Only the configuration
+ * nerf/run_nerf_acc.py:168-183 builds is accelerated: ReLU, no skip block,
+ * no view-direction head, one output channel. */
+typedef struct afx_model_desc {
+  int32_t n_in;        /* num_input_channels (3)                              */
+  int32_t enc;         /* AFX_ENC_*                                           */
+  int32_t n_freq;      /* pos_enc_basis L (ignored for AFX_ENC_NONE)          */
+  int32_t width;       /* num_filters: 64, 128 or 256                         */
+  int32_t n_hidden;    /* num_early_layers N  (Linear count = N + 2)          */
+} afx_model_desc;
+
+/* Flat fp32 parameter buffer layout (same order as the state-dict of the
+ * reference): W0[width,K0] b0[width] W1[width,width] b1 ... WN bN
+ * Wout[1,width] bout[1], K0 = n_in (+ 2*n_in*n_freq when encoded).           */
+
+int  afx_create(const afx_model_desc* desc, afx_ctx** out);
+void afx_destroy(afx_ctx* ctx);
+const char* afx_last_error(void);
+
+enum afx_query_what {
+  AFX_Q_PARAM_COUNT = 0,       /* floats in the flat parameter buffer               */
+  AFX_Q_K0 = 1,                /* encoded input width                               */
+  AFX_Q_PREPARED_BYTES = 2,    /* bytes of the prepared-weights buffer (arg = prec) */
+  AFX_Q_FWD_WORKSPACE = 3,     /* bytes needed by afx_render_forward  (arg0 = n_rays, arg1 = n_samples) */
+  AFX_Q_BWD_WORKSPACE_MIN = 4, /* smallest sensible backward workspace (arg0 = n_rays, 0 for afx_mlp_backward) */
+  AFX_Q_BWD_WORKSPACE_FULL = 5 /* workspace that lets backward run in one chunk (arg0 = n_rays, arg1 = n_samples; afx_mlp_backward: arg0 = 0, arg1 = n_pts) */
+};
+int64_t afx_query(const afx_ctx* ctx, int what, int64_t arg0, int64_t arg1, int64_t arg2);
+
+/* Offset (in floats) and shape of linear layer `layer` (0 .. n_hidden+1) inside
+ * the flat parameter buffer. */
+int afx_param_layout(const afx_ctx* ctx, int layer, int64_t* w_off, int64_t* b_off,
+                     int32_t* rows, int32_t* cols);
+
+/* Re-tile the flat fp32 parameters into the MFMA operand order the kernels
+ * stream through LDS (forward slabs, transposed slabs for the input-gradient
+ * chain, permuted biases).  Must be re-run after every optimizer step.
+ * enc_aux: BARF: 2*n_in*n_freq floats = [freq | weight] (CPPN.barf_freq,
+ * CPPN.barf_weights, model/CPPN.py:84-85,244-259); FOURIER: n_in*n_freq
+ * coefficients (CPPN.py:73-75); may be NULL for AFX_ENC_NONE. */
+int afx_prepare_weights(afx_ctx* ctx, int prec, const float* params, const float* enc_aux,
+                        void* prepared, size_t prepared_bytes, void* stream);
+
+/* get_predictions(model, flattened_query_points, chunksize) — nerf/nerf_helpers.py:31-45
+ * and get_predictions_vis — visualization/helpers.py:21-45 (density grid).
+ * pts[P,3] fp32 -> out[P] = raw, or sigmoid(raw) when apply_sigmoid != 0.
+ * The chunk loop of the reference is unnecessary (nothing is materialised). */
+int afx_mlp_infer(afx_ctx* ctx, int prec, const void* prepared, const float* pts, int64_t n_pts,
+                  float* out, int apply_sigmoid, void* stream);
+
+/* Backward of afx_mlp_infer (apply_sigmoid = 0): grad_flat += d(sum_p d_out[p]*raw[p])/d(params).
+ * This is what loss.backward() does through get_predictions (nerf/run_nerf_acc.py:294,306)
+ * when compositing is done outside the fused kernel. */
+int afx_mlp_backward(afx_ctx* ctx, int prec, const void* prepared, const float* pts, int64_t n_pts,
+                     const float* d_out, float* grad_flat, void* workspace, size_t workspace_bytes,
+                     void* stream);
+
+/* Where rays come from. */
+enum { AFX_RAYS_ARRAYS = 0,   /* origins[R,3], dirs[R,3] fp32 (sample_pixel_rays output, nerf_helpers.py:137-150) */
+       AFX_RAYS_POSE = 1 };   /* generated in-kernel: get_ray_values, phantomdata/helpers.py:156-175 */
+/* Where depths along a ray come from, and which compositing convention. */
+enum { AFX_DEPTH_UNIFORM_MID = 0, /* t_s = near+i*step, t_e = t_s+step, evaluate at (t_s+t_e)/2, dt = t_e-t_s:
+                                     acc_ray_marching w/o grid + acc_render_volume_density, nerf_helpers_acc.py:10-63 */
+       AFX_DEPTH_SHARED_Z = 1,    /* z[S] shared by all rays; render_volume_density, nerf_helpers.py:59-123:
+                                     dt_i = (z[i+1]-z[i])*||d||, last dt = 1e10*||d||                                   */
+       AFX_DEPTH_PER_RAY_Z = 2 }; /* z[R,S] (hierarchical sampling, nerf_helpers.py:178-195); same convention   */
+
+typedef struct afx_render_args {
+  int64_t n_rays;
+  int32_t n_samples;           /* S, samples per ray                                     */
+  int32_t ray_mode;            /* AFX_RAYS_*                                             */
+  const float* origins;        /* [R,3]  (AFX_RAYS_ARRAYS)                               */
+  const float* dirs;           /* [R,3]                                                  */
+  const double* poses;         /* [n_proj,3,4] row-major cam->world (AFX_RAYS_POSE), device */
+  const int32_t* ray_ids;      /* [R] index into [n_proj,H,W]; NULL => ray r is index ray_id0 + r */
+  int64_t ray_id0;
+  int32_t width, height;
+  double focal;
+  int32_t depth_mode;          /* AFX_DEPTH_*                                            */
+  float t_near, t_far;         /* AFX_DEPTH_UNIFORM_MID                                  */
+  const float* z;              /* [S] or [R,S]                                           */
+  float* pixel;                /* out [R]: rgb_map (transmittance)                       */
+  float* sigma;                /* optional out [R,S]: sigmoid(raw)                       */
+  float* tau;                  /* optional out [R,S]: sigma*dt (optical depth per sample) */
+  void* workspace;
+  size_t workspace_bytes;
+} afx_render_args;
+
+/* Fused ray generation -> sampling -> encoding -> MLP -> Beer-Lambert product.
+ * Replaces the body of nerf/run_nerf_acc.py:287-296 (and :340-349 for eval). */
+int afx_render_forward(afx_ctx* ctx, int prec, const void* prepared, const afx_render_args* args,
+                       void* stream);
+
+/* Backward of afx_render_forward w.r.t. the flat parameters:
+ * grad_flat[param_count] += d(sum_r dL_dpixel[r] * pixel[r]) / d(params).
+ * `pixel` in args must hold the forward result.  Replaces loss.backward()
+ * through nerf/run_nerf_acc.py:289-296.  The workspace bounds the ray chunk
+ * processed per pass (activations are recomputed, then stashed per chunk for
+ * the weight-gradient contraction over samples). */
+int afx_render_backward(afx_ctx* ctx, int prec, const void* prepared, const afx_render_args* args,
+                        const float* dL_dpixel, float* grad_flat, void* stream);
+
+/* render_volume_density(radiance_field, ray_directions, depth_values) for one output channel —
+ * nerf/nerf_helpers.py:59-123 (C == 1 branch), from a raw tensor already in memory.
+ * raw[R,S], dirs[R,3], z[S] (z_per_ray=0) or [R,S]; all outputs optional except rgb_map.
+ * weights = (1-alpha+1e-10)*cumprod_exclusive(alpha); depth_map = sum(alpha*z) (sic);
+ * entropy per nerf_helpers.py:125-135. */
+int afx_composite_dense(const float* raw, const float* dirs, const float* z, int z_per_ray,
+                        int64_t n_rays, int32_t n_samples, float* rgb_map, float* depth_map,
+                        float* weights, float* entropy, float* sigma, void* stream);
+/* d raw = backward of rgb_map only (the quantity the loss uses). */
+int afx_composite_dense_backward(const float* raw, const float* dirs, const float* z, int z_per_ray,
+                                 int64_t n_rays, int32_t n_samples, const float* rgb_map,
+                                 const float* d_rgb_map, float* d_raw, void* stream);
+
+/* acc_render_volume_density(predictions, ray_indices, t_starts, t_ends, n_rays, ...) —
+ * nerf/nerf_helpers_acc.py:45-63.  ray_indices must be sorted ascending (packed samples,
+ * as nerfacc.ray_marching returns them).  rgb_map[r] = prod_{i in ray r} exp(-sigmoid(pred_i)*(te_i-ts_i)). */
+int afx_composite_packed(const float* pred, const int32_t* ray_indices, const float* t_starts,
+                         const float* t_ends, int64_t n, int64_t n_rays, float* rgb_map, void* stream);
+int afx_composite_packed_backward(const float* pred, const int32_t* ray_indices, const float* t_starts,
+                                  const float* t_ends, int64_t n, int64_t n_rays, const float* rgb_map,
+                                  const float* d_rgb_map, float* d_pred, void* stream);
+
+/* sample_pdf(bins, weights, N_samples) — nerf/nerf_helpers.py:197-222, with the uniform
+ * draw u[R,n_fine] supplied by the caller; and the depth part of fine_sampling (:179-186):
+ * bins = mid-points of z_coarse, weights = w_coarse[:,1:-1], output = sort(cat(z_coarse, samples)).
+ * z_coarse [S] (z_per_ray=0) or [R,S]; w_coarse[R,S]; z_out[R,S+n_fine]. */
+int afx_fine_depths(const float* z_coarse, int z_per_ray, const float* w_coarse, const float* u,
+                    int64_t n_rays, int32_t n_coarse, int32_t n_fine, float* z_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AFX_H */

@@ -1,0 +1,88 @@
+"""ctypes binding of libafx.so (include/afx.h).  There is NO fallback: if the HIP library is
+missing or a call fails, an exception is raised."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libafx.so")
+
+ENC = {"none": 0, "barf": 1, "fourier": 2}
+PREC = {"f32": 0, "bf16x3": 1, "bf16": 2}
+RAYS_ARRAYS, RAYS_POSE = 0, 1
+DEPTH_UNIFORM_MID, DEPTH_SHARED_Z, DEPTH_PER_RAY_Z = 0, 1, 2
+Q_PARAM_COUNT, Q_K0, Q_PREPARED_BYTES, Q_FWD_WORKSPACE, Q_BWD_WORKSPACE_MIN, Q_BWD_WORKSPACE_FULL = range(6)
+
+
+class AfxError(RuntimeError):
+    pass
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [("n_in", C.c_int32), ("enc", C.c_int32), ("n_freq", C.c_int32), ("width", C.c_int32),
+                ("n_hidden", C.c_int32)]
+
+
+class RenderArgs(C.Structure):
+    _fields_ = [("n_rays", C.c_int64), ("n_samples", C.c_int32), ("ray_mode", C.c_int32),
+                ("origins", C.c_void_p), ("dirs", C.c_void_p), ("poses", C.c_void_p), ("ray_ids", C.c_void_p),
+                ("ray_id0", C.c_int64), ("width", C.c_int32), ("height", C.c_int32), ("focal", C.c_double),
+                ("depth_mode", C.c_int32), ("t_near", C.c_float), ("t_far", C.c_float), ("z", C.c_void_p),
+                ("pixel", C.c_void_p), ("sigma", C.c_void_p), ("tau", C.c_void_p), ("workspace", C.c_void_p),
+                ("workspace_bytes", C.c_size_t)]
+
+
+_SIGS = {
+    "afx_create": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(C.c_void_p)]),
+    "afx_destroy": (None, [C.c_void_p]),
+    "afx_last_error": (C.c_char_p, []),
+    "afx_query": (C.c_int64, [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int64]),
+    "afx_param_layout": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                   C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "afx_prepare_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "afx_mlp_infer": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),
+    "afx_mlp_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_size_t, C.c_void_p]),
+    "afx_render_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(RenderArgs), C.c_void_p]),
+    "afx_render_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(RenderArgs), C.c_void_p, C.c_void_p,
+                                      C.c_void_p]),
+    "afx_composite_dense": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int32, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "afx_composite_dense_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int32,
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "afx_composite_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
+                                       C.c_void_p]),
+    "afx_composite_packed_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "afx_fine_depths": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                  C.c_void_p, C.c_void_p]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    """Every entry point include/afx.h declares."""
+    return sorted(_SIGS)
+
+
+def load():
+    """Load libafx.so; raise loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AfxError(f"HIP library not built: {LIB_PATH} is missing. Run `python -m nerf_for_angiography_amd.build` "
+                       "(needs hipcc, --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what="afx call"):
+    if rc != 0:
+        msg = load().afx_last_error()
+        raise AfxError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,427 @@
+// afx_api.hip — host side of the C-ABI declared in include/afx.h.
+// Validates arguments, carves the caller-owned workspace, launches the gfx950 kernels.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string>
+#include "../../include/afx.h"
+#include "afx_internal.h"
+#include "afx_kernels_f32.hip"
+
+using namespace afx;
+
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIPCHK(x)                                                                         \
+  do {                                                                                    \
+    hipError_t e_ = (x);                                                                  \
+    if (e_ != hipSuccess) return fail(AFX_E_HIP, "%s -> %s (%d)", #x, hipGetErrorString(e_), (int)e_); \
+  } while (0)
+
+struct afx_ctx {
+  afx_model_desc d;
+  int k0, nq, k0pad, nt;
+  int64_t n_params;
+  int n_cu;
+  bool attr_set[2];
+};
+
+static inline uint32_t rup(uint64_t v, uint64_t a) { return (uint32_t)((v + a - 1) / a * a); }
+static inline size_t rup64(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Layout of the prepared-weights buffer for one precision.
+struct PrepLayout {
+  uint32_t small_floats, small_bytes_pad, slab0_bytes, slabh_bytes, slot_bytes;
+  uint32_t small_off, slab0_off, fwd_off, bwd_off;
+  size_t total;
+};
+
+static PrepLayout prep_layout(const afx_ctx* c, int prec) {
+  (void)prec;
+  PrepLayout L;
+  const int F = c->d.width, N = c->d.n_hidden, NT = c->nt;
+  const int naux = c->d.enc == AFX_ENC_BARF ? 6 * c->d.n_freq : (c->d.enc == AFX_ENC_FOURIER ? 3 * c->d.n_freq : 0);
+  L.small_floats = rup((uint64_t)(N + 2) * F + 4 + naux, 4);
+  L.small_bytes_pad = rup((uint64_t)L.small_floats * 4, 1024);
+  L.slab0_bytes = rup((uint64_t)c->nq * NT * 256, 4096);
+  L.slabh_bytes = (uint32_t)NT * 4 * 1024;
+  L.slot_bytes = L.slab0_bytes > L.slabh_bytes ? L.slab0_bytes : L.slabh_bytes;
+  L.small_off = 0;
+  L.slab0_off = rup((uint64_t)L.small_floats * 4, 4096);
+  L.fwd_off = L.slab0_off + L.slab0_bytes;          // contiguous with slab0: one forward stream
+  L.bwd_off = L.fwd_off + (uint32_t)N * NT * L.slabh_bytes;
+  L.total = (size_t)L.bwd_off + (size_t)N * NT * L.slabh_bytes;
+  return L;
+}
+
+extern "C" const char* afx_last_error(void) { return g_err.c_str(); }
+
+extern "C" int afx_create(const afx_model_desc* d, afx_ctx** out) {
+  if (!d || !out) return fail(AFX_E_INVALID, "afx_create: null argument");
+  if (d->n_in != 3) return fail(AFX_E_INVALID, "afx_create: n_in must be 3 (got %d)", d->n_in);
+  if (d->width != 64 && d->width != 128 && d->width != 256)
+    return fail(AFX_E_INVALID, "afx_create: width must be 64, 128 or 256 (got %d)", d->width);
+  if (d->n_hidden < 1 || d->n_hidden > 16) return fail(AFX_E_INVALID, "afx_create: n_hidden must be in 1..16 (got %d)", d->n_hidden);
+  if (d->enc < AFX_ENC_NONE || d->enc > AFX_ENC_FOURIER) return fail(AFX_E_INVALID, "afx_create: bad enc %d", d->enc);
+  if (d->enc != AFX_ENC_NONE && (d->n_freq < 1 || d->n_freq > 10))
+    return fail(AFX_E_INVALID, "afx_create: n_freq must be in 1..10 (got %d)", d->n_freq);
+  afx_ctx* c = new afx_ctx();
+  c->d = *d;
+  if (d->enc == AFX_ENC_NONE) c->d.n_freq = 0;
+  c->k0 = 3 + 6 * c->d.n_freq;
+  c->nq = (c->k0 + 1) / 2;
+  c->k0pad = 2 * c->nq;
+  c->nt = d->width / 32;
+  if (c->k0pad > d->width) { delete c; return fail(AFX_E_INVALID, "afx_create: encoded width %d exceeds layer width", c->k0pad); }
+  const int64_t F = d->width;
+  c->n_params = F * c->k0 + F + (int64_t)d->n_hidden * (F * F + F) + F + 1;
+  int dev = 0;
+  hipDeviceProp_t prop;
+  c->n_cu = 256;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+    c->n_cu = prop.multiProcessorCount;
+  c->attr_set[0] = c->attr_set[1] = false;
+  *out = c;
+  return AFX_OK;
+}
+
+extern "C" void afx_destroy(afx_ctx* c) { delete c; }
+
+extern "C" int afx_param_layout(const afx_ctx* c, int layer, int64_t* w_off, int64_t* b_off, int32_t* rows, int32_t* cols) {
+  if (!c) return fail(AFX_E_INVALID, "afx_param_layout: null ctx");
+  const int64_t F = c->d.width;
+  const int N = c->d.n_hidden;
+  if (layer < 0 || layer > N + 1) return fail(AFX_E_INVALID, "afx_param_layout: layer %d out of range", layer);
+  int64_t wo, bo;
+  int r, cc;
+  if (layer == 0) { wo = 0; bo = F * c->k0; r = (int)F; cc = c->k0; }
+  else if (layer <= N) { wo = F * c->k0 + F + (int64_t)(layer - 1) * (F * F + F); bo = wo + F * F; r = (int)F; cc = (int)F; }
+  else { wo = F * c->k0 + F + (int64_t)N * (F * F + F); bo = wo + F; r = 1; cc = (int)F; }
+  if (w_off) *w_off = wo;
+  if (b_off) *b_off = bo;
+  if (rows) *rows = r;
+  if (cols) *cols = cc;
+  return AFX_OK;
+}
+
+// Backward workspace: fixed part + per-tile part.
+struct BwdLayout {
+  size_t dod_off, fixed_bytes, per_tile_bytes;
+};
+static const int kSplits = 64;
+static BwdLayout bwd_layout(const afx_ctx* c, int64_t n_rays) {
+  const size_t F = c->d.width, N = c->d.n_hidden;
+  BwdLayout B;
+  B.dod_off = 0;
+  size_t fixed = rup64((size_t)n_rays * 4, 256);   // dod (rays mode only)
+  fixed += rup64((N + 1) * (size_t)kSplits * F * F * 4, 256);     // partial
+  fixed += rup64((N + 2) * (size_t)kSplits * (F + 4) * 4, 256);   // partial2
+  B.fixed_bytes = fixed;
+  B.per_tile_bytes = (size_t)TILE * 4 * (2 * (N + 1) * F + c->k0pad + 1);
+  return B;
+}
+
+static int64_t s_pad_of(int s) { return (int64_t)(s + GROUP - 1) / GROUP * GROUP; }
+
+extern "C" int64_t afx_query(const afx_ctx* c, int what, int64_t a0, int64_t a1, int64_t a2) {
+  if (!c) { fail(AFX_E_INVALID, "afx_query: null ctx"); return -1; }
+  switch (what) {
+    case AFX_Q_PARAM_COUNT: return c->n_params;
+    case AFX_Q_K0: return c->k0;
+    case AFX_Q_PREPARED_BYTES: return (int64_t)prep_layout(c, (int)a0).total;
+    case AFX_Q_FWD_WORKSPACE: return (int64_t)rup64((size_t)a0 * (size_t)(s_pad_of((int)a1) / GROUP) * 4, 256);
+    case AFX_Q_BWD_WORKSPACE_MIN: {
+      BwdLayout B = bwd_layout(c, a0);
+      return (int64_t)(B.fixed_bytes + 32 * B.per_tile_bytes);
+    }
+    case AFX_Q_BWD_WORKSPACE_FULL: {
+      BwdLayout B = bwd_layout(c, a0);
+      const int64_t samples = a0 > 0 ? a0 * s_pad_of((int)a1) : a1;
+      const int64_t tiles = (samples + TILE - 1) / TILE;
+      return (int64_t)(B.fixed_bytes + (size_t)tiles * B.per_tile_bytes);
+    }
+  }
+  fail(AFX_E_INVALID, "afx_query: unknown query %d", what);
+  (void)a2;
+  return -1;
+}
+
+extern "C" int afx_prepare_weights(afx_ctx* c, int prec, const float* params, const float* enc_aux, void* prepared,
+                                   size_t prepared_bytes, void* stream) {
+  if (!c || !params || !prepared) return fail(AFX_E_INVALID, "afx_prepare_weights: null argument");
+  if (prec != AFX_PREC_F32) return fail(AFX_E_INVALID, "afx_prepare_weights: precision %d not built", prec);
+  if (c->d.enc != AFX_ENC_NONE && !enc_aux) return fail(AFX_E_INVALID, "afx_prepare_weights: enc_aux required for this encoding");
+  const PrepLayout L = prep_layout(c, prec);
+  if (prepared_bytes < L.total) return fail(AFX_E_WORKSPACE, "afx_prepare_weights: prepared buffer %zu < %zu bytes", prepared_bytes, L.total);
+  PrepArgs p;
+  p.params = params; p.enc_aux = enc_aux; p.prepared = (char*)prepared;
+  p.F = c->d.width; p.n_hidden = c->d.n_hidden; p.k0 = c->k0; p.nq = c->nq; p.enc = c->d.enc; p.n_freq = c->d.n_freq;
+  p.small_off = L.small_off; p.slab0_off = L.slab0_off; p.fwd_off = L.fwd_off; p.bwd_off = L.bwd_off;
+  p.slab0_bytes = L.slab0_bytes; p.slabh_bytes = L.slabh_bytes; p.small_floats = L.small_floats;
+  hipLaunchKernelGGL(k_prepare_f32, dim3(512), dim3(256), 0, (hipStream_t)stream, p);
+  HIPCHK(hipGetLastError());
+  return AFX_OK;
+}
+
+template <int F, bool BWD>
+static int launch_chain_t(afx_ctx* c, const ChainArgs& a, size_t lds_bytes, int grid, hipStream_t st) {
+  auto kern = k_chain_f32<F, BWD>;
+  if (!c->attr_set[BWD ? 1 : 0]) {
+    HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    c->attr_set[BWD ? 1 : 0] = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, st, a);
+  HIPCHK(hipGetLastError());
+  return AFX_OK;
+}
+
+static int launch_chain(afx_ctx* c, bool bwd, const ChainArgs& a, hipStream_t st) {
+  const int F = c->d.width, N = c->d.n_hidden;
+  size_t lds = (size_t)a.small_bytes_pad + 2 * (size_t)a.slot_bytes;
+  if (bwd) lds += (size_t)(N + 1) * ((c->nt + 1) / 2) * 256 * 4;
+  if (lds > 160 * 1024) return fail(AFX_E_INVALID, "model needs %zu B of LDS (> 160 KiB)", lds);
+  const int tiles = a.tile1 - a.tile0;
+  if (tiles <= 0) return AFX_OK;
+  const int grid = tiles < c->n_cu ? tiles : c->n_cu;
+  if (F == 64) return bwd ? launch_chain_t<64, true>(c, a, lds, grid, st) : launch_chain_t<64, false>(c, a, lds, grid, st);
+  if (F == 128) return bwd ? launch_chain_t<128, true>(c, a, lds, grid, st) : launch_chain_t<128, false>(c, a, lds, grid, st);
+  return bwd ? launch_chain_t<256, true>(c, a, lds, grid, st) : launch_chain_t<256, false>(c, a, lds, grid, st);
+}
+
+static void fill_model(const afx_ctx* c, int prec, const void* prepared, ChainArgs& a) {
+  const PrepLayout L = prep_layout(c, prec);
+  const char* base = (const char*)prepared;
+  a.stream_fwd = base + L.slab0_off;
+  a.stream_bwd = base + L.bwd_off;
+  a.small = (const float*)(base + L.small_off);
+  a.small_floats = L.small_floats; a.small_bytes_pad = L.small_bytes_pad;
+  a.slab0_bytes = L.slab0_bytes; a.slabh_bytes = L.slabh_bytes; a.slot_bytes = L.slot_bytes;
+  a.n_hidden = c->d.n_hidden; a.k0 = c->k0; a.nq = c->nq; a.enc = c->d.enc; a.n_freq = c->d.n_freq;
+}
+
+extern "C" int afx_mlp_infer(afx_ctx* c, int prec, const void* prepared, const float* pts, int64_t n_pts, float* out,
+                             int apply_sigmoid, void* stream) {
+  if (!c || !prepared || !pts || !out) return fail(AFX_E_INVALID, "afx_mlp_infer: null argument");
+  if (prec != AFX_PREC_F32) return fail(AFX_E_INVALID, "afx_mlp_infer: precision %d not built", prec);
+  if (n_pts < 0 || n_pts > (int64_t)1 << 37) return fail(AFX_E_INVALID, "afx_mlp_infer: bad n_pts");
+  if (n_pts == 0) return AFX_OK;
+  ChainArgs a = {};
+  fill_model(c, prec, prepared, a);
+  const int64_t tiles = (n_pts + TILE - 1) / TILE;
+  if (tiles > 0x7fffffff) return fail(AFX_E_INVALID, "afx_mlp_infer: too many points for one call");
+  a.tile0 = 0; a.tile1 = (int)tiles; a.n_total = n_pts; a.mode = 0;
+  a.pts = pts; a.out = out; a.apply_sigmoid = apply_sigmoid;
+  return launch_chain(c, false, a, (hipStream_t)stream);
+}
+
+static int check_render(const afx_ctx* c, const afx_render_args* r, const char* who) {
+  if (!c || !r) return fail(AFX_E_INVALID, "%s: null argument", who);
+  if (r->n_rays < 0) return fail(AFX_E_INVALID, "%s: n_rays < 0", who);
+  if (r->n_samples < 2 || r->n_samples > 4096) return fail(AFX_E_INVALID, "%s: n_samples must be in 2..4096 (got %d)", who, r->n_samples);
+  if (r->ray_mode == AFX_RAYS_ARRAYS) {
+    if (!r->origins || !r->dirs) return fail(AFX_E_INVALID, "%s: origins/dirs required", who);
+  } else if (r->ray_mode == AFX_RAYS_POSE) {
+    if (!r->poses || r->width <= 0 || r->height <= 0 || !(r->focal > 0)) return fail(AFX_E_INVALID, "%s: poses/width/height/focal required", who);
+  } else return fail(AFX_E_INVALID, "%s: bad ray_mode %d", who, r->ray_mode);
+  if (r->depth_mode == AFX_DEPTH_UNIFORM_MID) {
+    if (!(r->t_far > r->t_near)) return fail(AFX_E_INVALID, "%s: need t_far > t_near", who);
+  } else if (r->depth_mode == AFX_DEPTH_SHARED_Z || r->depth_mode == AFX_DEPTH_PER_RAY_Z) {
+    if (!r->z) return fail(AFX_E_INVALID, "%s: z required for this depth_mode", who);
+  } else return fail(AFX_E_INVALID, "%s: bad depth_mode %d", who, r->depth_mode);
+  if (!r->pixel) return fail(AFX_E_INVALID, "%s: pixel required", who);
+  if (r->n_rays * s_pad_of(r->n_samples) > ((int64_t)1 << 31) - TILE)
+    return fail(AFX_E_INVALID, "%s: n_rays*padded samples must be < 2^31 per call; split the ray batch", who);
+  return AFX_OK;
+}
+
+static void fill_render(const afx_render_args* r, ChainArgs& a) {
+  a.mode = 1;
+  a.org = r->origins; a.dir = r->dirs;
+  a.poses = r->ray_mode == AFX_RAYS_POSE ? r->poses : nullptr;
+  a.ray_ids = r->ray_ids; a.ray_id0 = r->ray_id0; a.width = r->width; a.height = r->height; a.focal = r->focal;
+  a.n_samples = r->n_samples; a.s_pad = (int)s_pad_of(r->n_samples); a.depth_mode = r->depth_mode;
+  a.t_near = r->t_near;
+  a.t_step = (float)((double)(r->t_far - r->t_near) / r->n_samples);
+  a.z = r->z;
+  a.n_total = r->n_rays * a.s_pad;
+  a.sigma = r->sigma; a.tau = r->tau;
+}
+
+extern "C" int afx_render_forward(afx_ctx* c, int prec, const void* prepared, const afx_render_args* r, void* stream) {
+  int rc = check_render(c, r, "afx_render_forward");
+  if (rc) return rc;
+  if (prec != AFX_PREC_F32) return fail(AFX_E_INVALID, "afx_render_forward: precision %d not built", prec);
+  if (!prepared) return fail(AFX_E_INVALID, "afx_render_forward: null prepared");
+  if (r->n_rays == 0) return AFX_OK;
+  const size_t need = (size_t)afx_query(c, AFX_Q_FWD_WORKSPACE, r->n_rays, r->n_samples, 0);
+  if (!r->workspace || r->workspace_bytes < need) return fail(AFX_E_WORKSPACE, "afx_render_forward: workspace %zu < %zu bytes", r->workspace_bytes, need);
+  hipStream_t st = (hipStream_t)stream;
+  ChainArgs a = {};
+  fill_model(c, prec, prepared, a);
+  fill_render(r, a);
+  a.od_part = (float*)r->workspace;
+  a.tile0 = 0; a.tile1 = (int)((a.n_total + TILE - 1) / TILE);
+  rc = launch_chain(c, false, a, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_finish_fwd, dim3((unsigned)((r->n_rays + 255) / 256)), dim3(256), 0, st, a.od_part, a.s_pad / GROUP, r->n_rays, r->pixel);
+  HIPCHK(hipGetLastError());
+  return AFX_OK;
+}
+
+template <int F>
+static int launch_wgrad_t(const WgradArgs& w, const ReduceArgs& rd, int N, hipStream_t st) {
+  hipLaunchKernelGGL(k_wgrad_f32<F>, dim3(w.n_splits, N + 1), dim3(512), 0, st, w);
+  hipLaunchKernelGGL(k_colsum_f32<F>, dim3(w.n_splits, N + 2), dim3(F), 0, st, w);
+  hipLaunchKernelGGL(k_reduce_w<F>, dim3((F * F + 255) / 256, N + 1), dim3(256), 0, st, rd);
+  hipLaunchKernelGGL(k_reduce_b<F>, dim3(1, N + 2), dim3(F), 0, st, rd);
+  HIPCHK(hipGetLastError());
+  return AFX_OK;
+}
+
+// Shared by afx_render_backward / afx_mlp_backward: chain (recompute + input-gradient chain +
+// stash) then the weight-gradient contraction, chunk by chunk.  `a` is fully filled except the
+// backward pointers; `head` bytes at the start of the workspace are already in use (dod).
+static int run_backward(afx_ctx* c, ChainArgs a, size_t head, char* ws, size_t ws_bytes, float* grad_flat, hipStream_t st) {
+  const int F = c->d.width, N = c->d.n_hidden;
+  const BwdLayout B = bwd_layout(c, 0);
+  const size_t fixed = head + B.fixed_bytes;
+  if (ws_bytes < fixed + B.per_tile_bytes) return fail(AFX_E_WORKSPACE, "backward workspace %zu too small (min %zu)", ws_bytes, fixed + 32 * B.per_tile_bytes);
+  const int64_t tiles = (a.n_total + TILE - 1) / TILE;
+  int64_t chunk = (int64_t)((ws_bytes - fixed) / B.per_tile_bytes);
+  if (chunk > tiles) chunk = tiles;
+  size_t off = head;
+  float* partial = (float*)(ws + off); off += rup64((size_t)(N + 1) * kSplits * F * F * 4, 256);
+  float* partial2 = (float*)(ws + off); off += rup64((size_t)(N + 2) * kSplits * (F + 4) * 4, 256);
+  const size_t rows = (size_t)chunk * TILE;
+  a.stash_h = (float*)(ws + off); off += (size_t)(N + 1) * rows * F * 4;
+  a.stash_dz = (float*)(ws + off); off += (size_t)(N + 1) * rows * F * 4;
+  a.stash_e = (float*)(ws + off); off += rows * c->k0pad * 4;
+  a.graw = (float*)(ws + off);
+  a.stash_rows = (int64_t)rows;
+  for (int64_t t0 = 0; t0 < tiles; t0 += chunk) {
+    const int64_t t1 = t0 + chunk < tiles ? t0 + chunk : tiles;
+    a.tile0 = (int)t0; a.tile1 = (int)t1;
+    int rc = launch_chain(c, true, a, st);
+    if (rc) return rc;
+    WgradArgs w;
+    w.stash_h = a.stash_h; w.stash_dz = a.stash_dz; w.stash_e = a.stash_e; w.graw = a.graw;
+    w.rows = (t1 - t0) * TILE;
+    w.stride_rows = (int64_t)rows;   // a short last chunk keeps the full-chunk layer stride
+    w.n_hidden = N; w.k0 = c->k0; w.k0pad = c->k0pad;
+    int splits = (int)(w.rows / 256);
+    if (splits < 1) splits = 1;
+    if (splits > kSplits) splits = kSplits;
+    w.n_splits = splits;
+    int64_t rps = (w.rows + splits - 1) / splits;
+    rps = (rps + 1) / 2 * 2;
+    w.rows_per_split = (int)rps;
+    w.partial = partial; w.partial2 = partial2;
+    ReduceArgs rd;
+    rd.partial = partial; rd.partial2 = partial2; rd.n_hidden = N; rd.k0 = c->k0; rd.k0pad = c->k0pad; rd.n_splits = splits;
+    rd.grad = grad_flat;
+    if (F == 64) rc = launch_wgrad_t<64>(w, rd, N, st);
+    else if (F == 128) rc = launch_wgrad_t<128>(w, rd, N, st);
+    else rc = launch_wgrad_t<256>(w, rd, N, st);
+    if (rc) return rc;
+  }
+  return AFX_OK;
+}
+
+extern "C" int afx_render_backward(afx_ctx* c, int prec, const void* prepared, const afx_render_args* r,
+                                   const float* dL_dpixel, float* grad_flat, void* stream) {
+  int rc = check_render(c, r, "afx_render_backward");
+  if (rc) return rc;
+  if (prec != AFX_PREC_F32) return fail(AFX_E_INVALID, "afx_render_backward: precision %d not built", prec);
+  if (!prepared || !dL_dpixel || !grad_flat) return fail(AFX_E_INVALID, "afx_render_backward: null argument");
+  if (r->n_rays == 0) return AFX_OK;
+  if (!r->workspace) return fail(AFX_E_WORKSPACE, "afx_render_backward: workspace required");
+  hipStream_t st = (hipStream_t)stream;
+  ChainArgs a = {};
+  fill_model(c, prec, prepared, a);
+  fill_render(r, a);
+  a.sigma = nullptr; a.tau = nullptr;
+  const size_t head = rup64((size_t)r->n_rays * 4, 256);
+  if (r->workspace_bytes < head) return fail(AFX_E_WORKSPACE, "afx_render_backward: workspace too small");
+  float* dod = (float*)r->workspace;
+  hipLaunchKernelGGL(k_finish_bwd, dim3((unsigned)((r->n_rays + 255) / 256)), dim3(256), 0, st, r->pixel, dL_dpixel, r->n_rays, dod);
+  a.dod = dod;
+  return run_backward(c, a, head, (char*)r->workspace, r->workspace_bytes, grad_flat, st);
+}
+
+extern "C" int afx_mlp_backward(afx_ctx* c, int prec, const void* prepared, const float* pts, int64_t n_pts,
+                                const float* d_out, float* grad_flat, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!c || !prepared || !pts || !d_out || !grad_flat || !workspace) return fail(AFX_E_INVALID, "afx_mlp_backward: null argument");
+  if (prec != AFX_PREC_F32) return fail(AFX_E_INVALID, "afx_mlp_backward: precision %d not built", prec);
+  if (n_pts < 0 || n_pts > ((int64_t)1 << 31) - TILE) return fail(AFX_E_INVALID, "afx_mlp_backward: n_pts must be < 2^31 per call");
+  if (n_pts == 0) return AFX_OK;
+  ChainArgs a = {};
+  fill_model(c, prec, prepared, a);
+  a.n_total = n_pts; a.mode = 0; a.pts = pts; a.dod = d_out;
+  return run_backward(c, a, 0, (char*)workspace, workspace_bytes, grad_flat, (hipStream_t)stream);
+}
+
+extern "C" int afx_composite_dense(const float* raw, const float* dirs, const float* z, int z_per_ray, int64_t n_rays,
+                                   int32_t n_samples, float* rgb_map, float* depth_map, float* weights, float* entropy,
+                                   float* sigma, void* stream) {
+  if (!raw || !dirs || !z || !rgb_map) return fail(AFX_E_INVALID, "afx_composite_dense: null argument");
+  if (n_samples < 1) return fail(AFX_E_INVALID, "afx_composite_dense: n_samples < 1");
+  if (n_rays <= 0) return AFX_OK;
+  hipLaunchKernelGGL(k_composite_dense, dim3((unsigned)((n_rays + 63) / 64)), dim3(64), 0, (hipStream_t)stream, raw, dirs, z,
+                     z_per_ray, n_rays, n_samples, rgb_map, depth_map, weights, entropy, sigma);
+  HIPCHK(hipGetLastError());
+  return AFX_OK;
+}
+
+extern "C" int afx_composite_dense_backward(const float* raw, const float* dirs, const float* z, int z_per_ray,
+                                            int64_t n_rays, int32_t n_samples, const float* rgb_map,
+                                            const float* d_rgb_map, float* d_raw, void* stream) {
+  if (!raw || !dirs || !z || !rgb_map || !d_rgb_map || !d_raw) return fail(AFX_E_INVALID, "afx_composite_dense_backward: null argument");
+  if (n_rays <= 0) return AFX_OK;
+  const int64_t n = n_rays * n_samples;
+  hipLaunchKernelGGL(k_composite_dense_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, raw, dirs, z,
+                     z_per_ray, n_rays, n_samples, rgb_map, d_rgb_map, d_raw);
+  HIPCHK(hipGetLastError());
+  return AFX_OK;
+}
+
+extern "C" int afx_composite_packed(const float* pred, const int32_t* ri, const float* ts, const float* te, int64_t n,
+                                    int64_t n_rays, float* rgb_map, void* stream) {
+  if (!rgb_map || (n > 0 && (!pred || !ri || !ts || !te))) return fail(AFX_E_INVALID, "afx_composite_packed: null argument");
+  if (n_rays <= 0) return AFX_OK;
+  hipLaunchKernelGGL(k_composite_packed, dim3((unsigned)((n_rays + 63) / 64)), dim3(64), 0, (hipStream_t)stream, pred, ri, ts, te,
+                     n, n_rays, rgb_map);
+  HIPCHK(hipGetLastError());
+  return AFX_OK;
+}
+
+extern "C" int afx_composite_packed_backward(const float* pred, const int32_t* ri, const float* ts, const float* te,
+                                             int64_t n, int64_t n_rays, const float* rgb_map, const float* d_rgb_map,
+                                             float* d_pred, void* stream) {
+  (void)n_rays;
+  if (n <= 0) return AFX_OK;
+  if (!pred || !ri || !ts || !te || !rgb_map || !d_rgb_map || !d_pred) return fail(AFX_E_INVALID, "afx_composite_packed_backward: null argument");
+  hipLaunchKernelGGL(k_composite_packed_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pred, ri, ts,
+                     te, n, rgb_map, d_rgb_map, d_pred);
+  HIPCHK(hipGetLastError());
+  return AFX_OK;
+}
+
+extern "C" int afx_fine_depths(const float* z_coarse, int z_per_ray, const float* w_coarse, const float* u, int64_t n_rays,
+                               int32_t n_coarse, int32_t n_fine, float* z_out, void* stream) {
+  if (!z_coarse || !w_coarse || !u || !z_out) return fail(AFX_E_INVALID, "afx_fine_depths: null argument");
+  if (n_coarse < 3 || n_coarse > AFX_MAX_COARSE) return fail(AFX_E_INVALID, "afx_fine_depths: n_coarse must be in 3..%d", AFX_MAX_COARSE);
+  if (n_fine < 1 || n_fine > AFX_MAX_FINE) return fail(AFX_E_INVALID, "afx_fine_depths: n_fine must be in 1..%d", AFX_MAX_FINE);
+  if (n_rays <= 0) return AFX_OK;
+  hipLaunchKernelGGL(k_fine_depths, dim3((unsigned)((n_rays + 63) / 64)), dim3(64), 0, (hipStream_t)stream, z_coarse, z_per_ray,
+                     w_coarse, u, n_rays, n_coarse, n_fine, z_out);
+  HIPCHK(hipGetLastError());
+  return AFX_OK;
+}

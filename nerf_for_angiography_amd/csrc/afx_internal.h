@@ -1,0 +1,72 @@
+// afx_internal.h — shared between the C-ABI host code and the gfx950 kernels.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+namespace afx {
+
+constexpr int TILE = 128;            // samples per workgroup tile (4 waves x 32 sample-columns)
+constexpr int GROUP = 32;            // samples per wave column group; s_pad is a multiple of this
+
+// Arguments of the fused chain kernels (by value, < 512 B).
+struct ChainArgs {
+  // prepared weights
+  const char* stream_fwd;   // slab0, then n_hidden*NT forward slabs (layer 1..N, tile 0..NT-1)
+  const char* stream_bwd;   // n_hidden*NT transposed slabs (layer N..1, tile 0..NT-1)
+  const float* small;       // permuted biases, output weights, bout, encoding aux
+  uint32_t small_floats;    // multiple of 4
+  uint32_t small_bytes_pad; // LDS bytes reserved for `small` (multiple of 1024)
+  uint32_t slab0_bytes, slabh_bytes, slot_bytes;   // multiples of 4096
+  int32_t n_hidden, k0, nq, enc, n_freq;
+  // work range
+  int32_t tile0, tile1;     // global tile ids [tile0, tile1)
+  int64_t n_total;          // samples: n_rays * s_pad, or n_pts
+  int32_t mode;             // 0 = points, 1 = rays
+  // inputs
+  const float* pts;
+  const float* org;
+  const float* dir;
+  const double* poses;
+  const int32_t* ray_ids;
+  int64_t ray_id0;
+  int32_t width, height;
+  double focal;
+  int32_t n_samples, s_pad, depth_mode;
+  float t_near, t_step;
+  const float* z;
+  // outputs
+  float* out;               // points mode
+  int32_t apply_sigmoid;
+  float* od_part;           // [R, s_pad/32]
+  float* sigma;             // optional [R,S]
+  float* tau;               // optional [R,S]
+  // backward only
+  const float* dod;         // [R] dL/d(optical depth)
+  float* stash_h;           // [(N+1), rows, F]   post-activation H_0..H_N
+  float* stash_dz;          // [(N+1), rows, F]   dL/dZ_0..dZ_N
+  float* stash_e;           // [rows, 2*nq]       encoded inputs
+  float* graw;              // [rows]             dL/draw
+  int64_t stash_rows;
+};
+
+struct WgradArgs {
+  const float* stash_h;
+  const float* stash_dz;
+  const float* stash_e;
+  const float* graw;
+  int64_t rows;             // rows to contract over (multiple of TILE)
+  int64_t stride_rows;      // layer stride of the stash (rows of a full chunk)
+  int32_t n_hidden, k0, k0pad;
+  int32_t n_splits, rows_per_split;   // rows_per_split even
+  float* partial;           // [(N+1), n_splits, F*F]
+  float* partial2;          // [(N+2), n_splits, F+4]
+};
+
+struct ReduceArgs {
+  const float* partial;
+  const float* partial2;
+  int32_t n_hidden, k0, k0pad, n_splits;
+  float* grad;              // flat parameter gradient, accumulated into
+};
+
+}  // namespace afx

@@ -1,0 +1,270 @@
+"""Host-side driver of libafx.so: owns the torch buffers (prepared weights, workspace) the C-ABI
+works on and exposes the fused kernels to the Python mirror of the reference interface.
+PyTorch is used for device memory and streams only."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import AfxError, ModelDesc, RenderArgs
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _f32(t: torch.Tensor, name: str, device) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise ValueError(f"{name}: expected a tensor")
+    if t.device != device:
+        raise ValueError(f"{name}: on {t.device}, expected {device}")
+    if t.dtype != torch.float32:
+        raise ValueError(f"{name}: dtype {t.dtype}, expected float32")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+@dataclass
+class RenderSpec:
+    """One ray batch for the fused renderer.
+
+    Rays: either origins/dirs [R,3] fp32 (what sample_pixel_rays returns), or poses [n_proj,3,4] float64 +
+    ray_ids (int32 index into [n_proj,H,W]; None => rays ray_id0 .. ray_id0+R-1) + width/height/focal
+    (in-kernel get_ray_values).  Depths: mode 'acc' (uniform mid-point march t_near..t_far, the convention of
+    nerf_helpers_acc.py), 'dense' with z [S] or [R,S] (render_volume_density convention)."""
+    n_rays: int
+    n_samples: int
+    origins: Optional[torch.Tensor] = None
+    dirs: Optional[torch.Tensor] = None
+    poses: Optional[torch.Tensor] = None
+    ray_ids: Optional[torch.Tensor] = None
+    ray_id0: int = 0
+    width: int = 0
+    height: int = 0
+    focal: float = 0.0
+    mode: str = "acc"
+    t_near: float = 0.0
+    t_far: float = 0.0
+    z: Optional[torch.Tensor] = None
+
+
+class Engine:
+    """One CPPN geometry on one GPU."""
+
+    def __init__(self, width: int, n_hidden: int, enc: str = "none", n_freq: int = 0,
+                 max_workspace_bytes: int = 24 << 30):
+        self.lib = _lib.load()
+        self.desc = ModelDesc(3, _lib.ENC[enc], int(n_freq), int(width), int(n_hidden))
+        h = C.c_void_p()
+        _lib.check(self.lib.afx_create(C.byref(self.desc), C.byref(h)), "afx_create")
+        self.h = h
+        self.width, self.n_hidden, self.enc = width, n_hidden, enc
+        self.param_count = int(self.lib.afx_query(h, _lib.Q_PARAM_COUNT, 0, 0, 0))
+        self.k0 = int(self.lib.afx_query(h, _lib.Q_K0, 0, 0, 0))
+        self.max_workspace_bytes = int(max_workspace_bytes)
+        self._prepared = {}      # prec -> (buffer, version key)
+        self._ws = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.afx_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # ---- parameter layout ------------------------------------------------------------------
+    def layout(self, layer: int):
+        wo, bo, r, c = C.c_int64(), C.c_int64(), C.c_int32(), C.c_int32()
+        _lib.check(self.lib.afx_param_layout(self.h, layer, C.byref(wo), C.byref(bo), C.byref(r), C.byref(c)),
+                   "afx_param_layout")
+        return wo.value, bo.value, r.value, c.value
+
+    @staticmethod
+    def _stream(device):
+        return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+    def _workspace(self, nbytes: int, device) -> torch.Tensor:
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
+            self._ws = None
+            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        return self._ws
+
+    # ---- weights -----------------------------------------------------------------------------
+    def prepare(self, flat: torch.Tensor, enc_aux: Optional[torch.Tensor], prec: str, key=None):
+        """Re-tile the flat parameters for `prec` unless `key` says the cached copy is current."""
+        if not flat.is_cuda:
+            raise AfxError("the fused MI355X path needs parameters on a GPU; there is no CPU fallback")
+        flat = _f32(flat, "flat parameters", flat.device)
+        if flat.numel() != self.param_count:
+            raise ValueError(f"flat parameters: {flat.numel()} floats, expected {self.param_count}")
+        p = _lib.PREC[prec]
+        cached = self._prepared.get(prec)
+        if cached is not None and key is not None and cached[1] == key and cached[0].device == flat.device:
+            return cached[0]
+        nbytes = int(self.lib.afx_query(self.h, _lib.Q_PREPARED_BYTES, p, 0, 0))
+        buf = cached[0] if cached is not None and cached[0].device == flat.device else torch.empty(
+            nbytes, dtype=torch.uint8, device=flat.device)
+        if enc_aux is not None:
+            enc_aux = _f32(enc_aux, "enc_aux", flat.device)
+        _lib.check(self.lib.afx_prepare_weights(self.h, p, _ptr(flat), _ptr(enc_aux), _ptr(buf), nbytes,
+                                                self._stream(flat.device)), "afx_prepare_weights")
+        self._prepared[prec] = (buf, key)
+        return buf
+
+    # ---- MLP on explicit points --------------------------------------------------------------
+    def infer(self, prepared: torch.Tensor, pts: torch.Tensor, prec: str, apply_sigmoid: bool = False):
+        dev = prepared.device
+        pts = _f32(pts, "points", dev)
+        if pts.dim() != 2 or pts.shape[1] != 3:
+            raise ValueError(f"points: shape {tuple(pts.shape)}, expected [P,3]")
+        out = torch.empty(pts.shape[0], dtype=torch.float32, device=dev)
+        _lib.check(self.lib.afx_mlp_infer(self.h, _lib.PREC[prec], _ptr(prepared), _ptr(pts), pts.shape[0], _ptr(out),
+                                          int(apply_sigmoid), self._stream(dev)), "afx_mlp_infer")
+        return out
+
+    def mlp_backward(self, prepared, pts, d_out, grad_flat, prec: str):
+        dev = prepared.device
+        pts = _f32(pts, "points", dev)
+        d_out = _f32(d_out, "d_out", dev)
+        n = pts.shape[0]
+        if d_out.numel() != n:
+            raise ValueError("d_out: one value per point expected")
+        full = int(self.lib.afx_query(self.h, _lib.Q_BWD_WORKSPACE_FULL, 0, n, 0))
+        ws = self._workspace(min(full, self.max_workspace_bytes), dev)
+        _lib.check(self.lib.afx_mlp_backward(self.h, _lib.PREC[prec], _ptr(prepared), _ptr(pts), n, _ptr(d_out),
+                                             _ptr(grad_flat), _ptr(ws), ws.numel(), self._stream(dev)),
+                   "afx_mlp_backward")
+
+    # ---- fused renderer ----------------------------------------------------------------------
+    def _render_args(self, spec: RenderSpec, dev, pixel, sigma=None, tau=None):
+        a = RenderArgs()
+        keep = []
+        a.n_rays, a.n_samples = int(spec.n_rays), int(spec.n_samples)
+        if spec.poses is not None:
+            poses = spec.poses
+            if poses.device != dev or poses.dtype != torch.float64:
+                raise ValueError("poses: expected a float64 tensor on the model's device")
+            poses = poses.contiguous().reshape(-1, 12)
+            keep.append(poses)
+            a.ray_mode, a.poses = _lib.RAYS_POSE, poses.data_ptr()
+            if spec.ray_ids is not None:
+                ids = spec.ray_ids
+                if ids.device != dev or ids.dtype != torch.int32 or ids.numel() != spec.n_rays:
+                    raise ValueError("ray_ids: expected int32 [n_rays] on the model's device")
+                ids = ids.contiguous()
+                keep.append(ids)
+                a.ray_ids = ids.data_ptr()
+            a.ray_id0, a.width, a.height, a.focal = int(spec.ray_id0), int(spec.width), int(spec.height), float(spec.focal)
+        else:
+            o, d = _f32(spec.origins, "origins", dev), _f32(spec.dirs, "dirs", dev)
+            if tuple(o.shape) != (spec.n_rays, 3) or tuple(d.shape) != (spec.n_rays, 3):
+                raise ValueError("origins/dirs: expected [n_rays,3]")
+            keep += [o, d]
+            a.ray_mode, a.origins, a.dirs = _lib.RAYS_ARRAYS, o.data_ptr(), d.data_ptr()
+        if spec.mode == "acc":
+            a.depth_mode, a.t_near, a.t_far = _lib.DEPTH_UNIFORM_MID, float(spec.t_near), float(spec.t_far)
+        elif spec.mode == "dense":
+            z = _f32(spec.z, "z", dev)
+            if z.dim() == 1 and z.shape[0] == spec.n_samples:
+                a.depth_mode = _lib.DEPTH_SHARED_Z
+            elif tuple(z.shape) == (spec.n_rays, spec.n_samples):
+                a.depth_mode = _lib.DEPTH_PER_RAY_Z
+            else:
+                raise ValueError(f"z: shape {tuple(z.shape)}, expected [S] or [R,S]")
+            keep.append(z)
+            a.z = z.data_ptr()
+        else:
+            raise ValueError(f"mode {spec.mode!r}: expected 'acc' or 'dense'")
+        a.pixel = pixel.data_ptr()
+        if sigma is not None:
+            a.sigma = sigma.data_ptr()
+        if tau is not None:
+            a.tau = tau.data_ptr()
+        return a, keep
+
+    def render_forward(self, prepared, spec: RenderSpec, prec: str, want_sigma=False, want_tau=False):
+        dev = prepared.device
+        pixel = torch.empty(spec.n_rays, dtype=torch.float32, device=dev)
+        sigma = torch.empty(spec.n_rays, spec.n_samples, dtype=torch.float32, device=dev) if want_sigma else None
+        tau = torch.empty(spec.n_rays, spec.n_samples, dtype=torch.float32, device=dev) if want_tau else None
+        a, keep = self._render_args(spec, dev, pixel, sigma, tau)
+        ws = self._workspace(int(self.lib.afx_query(self.h, _lib.Q_FWD_WORKSPACE, spec.n_rays, spec.n_samples, 0)), dev)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+        _lib.check(self.lib.afx_render_forward(self.h, _lib.PREC[prec], _ptr(prepared), C.byref(a), self._stream(dev)),
+                   "afx_render_forward")
+        del keep
+        return pixel, sigma, tau
+
+    def render_backward(self, prepared, spec: RenderSpec, pixel, d_pixel, grad_flat, prec: str):
+        dev = prepared.device
+        pixel = _f32(pixel, "pixel", dev)
+        d_pixel = _f32(d_pixel, "d_pixel", dev)
+        a, keep = self._render_args(spec, dev, pixel)
+        full = int(self.lib.afx_query(self.h, _lib.Q_BWD_WORKSPACE_FULL, spec.n_rays, spec.n_samples, 0))
+        ws = self._workspace(min(full, self.max_workspace_bytes), dev)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+        _lib.check(self.lib.afx_render_backward(self.h, _lib.PREC[prec], _ptr(prepared), C.byref(a), _ptr(d_pixel),
+                                                _ptr(grad_flat), self._stream(dev)), "afx_render_backward")
+        del keep
+
+
+# ---- stand-alone compositing / sampling kernels (no model) -----------------------------------
+def composite_dense(raw, dirs, z, want_aux=True):
+    lib = _lib.load()
+    dev = raw.device
+    raw, dirs, z = _f32(raw, "raw", dev), _f32(dirs, "dirs", dev), _f32(z, "z", dev)
+    r, s = raw.shape
+    rgb = torch.empty(r, device=dev)
+    depth = torch.empty(r, device=dev) if want_aux else None
+    w = torch.empty(r, s, device=dev) if want_aux else None
+    ent = torch.empty(r, device=dev) if want_aux else None
+    sig = torch.empty(r, s, device=dev) if want_aux else None
+    _lib.check(lib.afx_composite_dense(_ptr(raw), _ptr(dirs), _ptr(z), int(z.dim() == 2), r, s, _ptr(rgb), _ptr(depth),
+                                       _ptr(w), _ptr(ent), _ptr(sig), Engine._stream(dev)), "afx_composite_dense")
+    return rgb, depth, w, ent, sig
+
+
+def composite_dense_backward(raw, dirs, z, rgb, d_rgb):
+    lib = _lib.load()
+    dev = raw.device
+    d_raw = torch.empty_like(raw)
+    r, s = raw.shape
+    _lib.check(lib.afx_composite_dense_backward(_ptr(raw), _ptr(dirs), _ptr(z), int(z.dim() == 2), r, s, _ptr(rgb),
+                                                _ptr(_f32(d_rgb, "d_rgb", dev)), _ptr(d_raw), Engine._stream(dev)),
+               "afx_composite_dense_backward")
+    return d_raw
+
+
+def composite_packed(pred, ray_indices, t_starts, t_ends, n_rays):
+    lib = _lib.load()
+    dev = pred.device
+    rgb = torch.empty(n_rays, device=dev)
+    _lib.check(lib.afx_composite_packed(_ptr(pred), _ptr(ray_indices), _ptr(t_starts), _ptr(t_ends), pred.numel(), n_rays,
+                                        _ptr(rgb), Engine._stream(dev)), "afx_composite_packed")
+    return rgb
+
+
+def composite_packed_backward(pred, ray_indices, t_starts, t_ends, n_rays, rgb, d_rgb):
+    lib = _lib.load()
+    dev = pred.device
+    d_pred = torch.empty_like(pred)
+    _lib.check(lib.afx_composite_packed_backward(_ptr(pred), _ptr(ray_indices), _ptr(t_starts), _ptr(t_ends), pred.numel(),
+                                                 n_rays, _ptr(rgb), _ptr(_f32(d_rgb, "d_rgb", dev)), _ptr(d_pred),
+                                                 Engine._stream(dev)), "afx_composite_packed_backward")
+    return d_pred
+
+
+def fine_depths(z_coarse, w_coarse, u):
+    lib = _lib.load()
+    dev = w_coarse.device
+    z_coarse, w_coarse, u = _f32(z_coarse, "z_coarse", dev), _f32(w_coarse, "w_coarse", dev), _f32(u, "u", dev)
+    r, s = w_coarse.shape
+    nf = u.shape[1]
+    out = torch.empty(r, s + nf, device=dev)
+    _lib.check(lib.afx_fine_depths(_ptr(z_coarse), int(z_coarse.dim() == 2), _ptr(w_coarse), _ptr(u), r, s, nf, _ptr(out),
+                                   Engine._stream(dev)), "afx_fine_depths")
+    return out

@@ -1,0 +1,77 @@
+"""Ray values / depth values / ground-truth projector — the hot-path part of the reference's
+phantomdata/helpers.py (:156-224), plus analytic synthetic phantoms (the reference's CT/STL data is private)."""
+import numpy as np
+import torch
+
+from .proj_helpers import source_matrix
+
+
+def rev_sigmoid(x, c1=1, c2=0):
+    """helpers.py:17-18."""
+    return 1 / (1 + np.exp(c1 * (x - c2)))
+
+
+def get_ray_values(theta, phi, larm, src_pt, img_width, img_height, focal_length, device, translation=np.array([0, 0, 0])):
+    """helpers.py:156-175 -> (ray_origins[H,W,3], ray_directions[H,W,3], src_matrix, ii, jj), float64."""
+    src_matrix = source_matrix(src_pt, theta, phi, larm, translation)
+    tform = torch.from_numpy(src_matrix).to(device)
+    ii, jj = torch.meshgrid(torch.arange(0, img_width).to(tform), torch.arange(0, img_height).to(tform), indexing='xy')
+    directions = torch.stack([(ii - img_width / 2) / focal_length, -(jj - img_height / 2) / focal_length,
+                              -torch.ones_like(ii)], dim=-1)
+    ray_directions = torch.sum(directions[..., None, :] * tform[:3, :3], dim=-1).to(device)
+    ray_origins = tform[:3, -1].expand(ray_directions.shape).to(device)
+    return ray_origins, ray_directions, src_matrix, ii, jj
+
+
+def get_depth_values(near_thresh, far_thresh, depth_samples_per_ray, device, stratified=True):
+    """helpers.py:177-190."""
+    t_vals = torch.linspace(0., 1., depth_samples_per_ray)
+    z_vals = near_thresh * (1. - t_vals) + far_thresh * t_vals
+    if stratified:
+        mids = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
+        upper = torch.cat([mids, z_vals[..., -1:]], -1)
+        lower = torch.cat([z_vals[..., :1], mids], -1)
+        z_vals = lower + (upper - lower) * torch.rand(z_vals.shape)
+    return z_vals.to(device)
+
+
+def capsule_tree(levels=5, seed=0, extent=75.0, r0=3.0, r1=0.75):
+    """Synthetic vessel tree: binary tree of 2^levels - 1 capsules inside +-extent -> [N,7] (a, b, radius)."""
+    rng = np.random.RandomState(seed)
+    segs, front = [], [(np.array([0.0, -0.8 * extent, 0.0]), np.array([0.0, 1.0, 0.0]), 0)]
+    n_total = 2 ** levels - 1
+    while front and len(segs) < n_total:
+        a, dirv, lev = front.pop(0)
+        b = np.clip(a + dirv * 0.55 * extent * (0.72 ** lev), -0.95 * extent, 0.95 * extent)
+        segs.append(np.concatenate([a, b, [r0 + (r1 - r0) * lev / max(levels - 1, 1)]]))
+        for sgn in (-1.0, 1.0):
+            nd = dirv + sgn * np.cross(dirv, [0.3, 0.2, 1.0]) * 0.8 + rng.normal(size=3) * 0.35
+            front.append((b, nd / np.linalg.norm(nd), lev + 1))
+    return np.asarray(segs, dtype=np.float32)
+
+
+def capsule_mu(points, capsules, mu=0.2):
+    """Binary attenuation field: mu inside any capsule, 0 outside. points [P,3] tensor (any device)."""
+    c = torch.as_tensor(capsules, dtype=points.dtype, device=points.device)
+    inside = torch.zeros(points.shape[0], dtype=torch.bool, device=points.device)
+    for i in range(c.shape[0]):
+        a, ab, r = c[i, 0:3], c[i, 3:6] - c[i, 0:3], c[i, 6]
+        t = ((points - a) @ ab / (ab @ ab)).clamp(0, 1)
+        inside |= torch.norm(points - (a + t[:, None] * ab), dim=-1) <= r
+    return inside.to(points.dtype) * mu
+
+
+def ray_tracing(mu_fn, ray_origins, ray_directions, depth_values, batch_rays=8192):
+    """Ground-truth X-ray projection (helpers.py:192-224, 'ct' branch) for a callable attenuation field:
+    img = prod_s exp(-mu(o + d z_s) * dz_s * ||d||), dz_last = 1e10 (harmless: mu(far plane) = 0)."""
+    shape = ray_origins.shape[:-1]
+    o, d = ray_origins.reshape(-1, 3), ray_directions.reshape(-1, 3)
+    big = torch.tensor([1e10], dtype=depth_values.dtype, device=depth_values.device)
+    dists = torch.cat((depth_values[1:] - depth_values[:-1], big), -1)
+    out = []
+    for i in range(0, o.shape[0], batch_rays):
+        oo, dd = o[i:i + batch_rays], d[i:i + batch_rays]
+        pts = oo[:, None, :] + dd[:, None, :] * depth_values[:, None]
+        mu = mu_fn(pts.reshape(-1, 3)).reshape(pts.shape[:-1]).to(depth_values.dtype)
+        out.append(torch.exp(-mu * dists * torch.norm(dd[:, None, :], dim=-1)).prod(-1))
+    return torch.cat(out).reshape(shape)

@@ -1,0 +1,126 @@
+"""Fused renderer: ray generation -> sampling -> CPPN -> Beer-Lambert product in one kernel pass per ray
+chunk, with autograd.  This is the path that replaces the body of the reference's training/eval
+iteration (nerf/run_nerf_acc.py:287-296, :340-349)."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from .engine import RenderSpec
+from ._lib import AfxError
+
+
+@dataclass
+class RenderOutput:
+    rgb_map: torch.Tensor                       # [R] transmittance = predicted pixel
+    depth_map: Optional[torch.Tensor] = None    # only with want_aux (dense convention)
+    weights: Optional[torch.Tensor] = None
+    entropy: Optional[torch.Tensor] = None
+    sigma: Optional[torch.Tensor] = None
+
+
+# Optional hook set by nerf_for_angiography_amd.dist: called on the flat gradient before it is split.
+_grad_hook = None
+
+
+class _RenderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, spec, want_st, *params):
+        prepared = model._prepared()
+        pixel, sigma, tau = model.engine.render_forward(prepared, spec, model.precision, want_sigma=want_st,
+                                                        want_tau=want_st)
+        ctx.model, ctx.spec = model, spec
+        ctx.save_for_backward(pixel)
+        if want_st:
+            ctx.mark_non_differentiable(sigma, tau)
+            return pixel, sigma, tau
+        return pixel
+
+    @staticmethod
+    def backward(ctx, d_pixel, *unused):
+        model, spec = ctx.model, ctx.spec
+        (pixel,) = ctx.saved_tensors
+        flat_grad = torch.zeros(model.engine.param_count, dtype=torch.float32, device=pixel.device)
+        model.engine.render_backward(model._prepared(), spec, pixel, d_pixel.contiguous(), flat_grad, model.precision)
+        if _grad_hook is not None:
+            _grad_hook(flat_grad)
+        return (None, None, None) + model._split_grad(flat_grad)
+
+
+def _check_model(model):
+    if not getattr(model, "fused", False):
+        raise NotImplementedError("render_rays: this CPPN configuration is outside the fused kernels "
+                                  "(ReLU, no skip block, no view directions, one output channel)")
+    if model.flat_params is None or not model.flat_params.is_cuda:
+        raise AfxError("render_rays: the model must live on a GPU; there is no CPU fallback")
+
+
+def render_spec(spec: RenderSpec, model, want_aux: bool = False) -> RenderOutput:
+    _check_model(model)
+    if model.use_pos_enc == "fourier" and torch.is_grad_enabled() and model.fourier_coefficients.requires_grad:
+        raise NotImplementedError("the fused kernels treat fourier_coefficients as constants")
+    if not want_aux:
+        return RenderOutput(_RenderFn.apply(model, spec, False, *model._hip_params()))
+    pixel, sigma, tau = _RenderFn.apply(model, spec, True, *model._hip_params())
+    out = RenderOutput(pixel, sigma=sigma)
+    if spec.mode == "dense":
+        # weights / depth_map / entropy of render_volume_density (nerf_helpers.py:107-119) from the
+        # per-sample optical depths the kernel wrote; cheap per-ray scans, no MLP work.
+        alpha = torch.exp(-tau)
+        excl = torch.cat([torch.ones_like(alpha[:, :1]), torch.cumprod(alpha, -1)[:, :-1]], -1)
+        out.weights = (1 - alpha + 1e-10) * excl
+        z = spec.z if spec.z.dim() == 2 else spec.z[None, :]
+        out.depth_map = (alpha * z).sum(-1)
+        dens = sigma / (sigma.sum(-1, keepdim=True) + 1e-10)
+        ent = -(dens * torch.log(dens + 1e-10)).sum(-1)
+        out.entropy = ent * ((1 - pixel.detach()) > 0.4)
+    return out
+
+
+def render_rays(model, ray_origins, ray_directions, depth_samples_per_ray: int = 0, near_thresh: float = 0.0,
+                far_thresh: float = 0.0, mode: str = "acc", z: Optional[torch.Tensor] = None,
+                want_aux: bool = False) -> RenderOutput:
+    """Pixels for rays given as origin/direction arrays (the output of sample_pixel_rays).
+
+    mode='acc'  : depth_samples_per_ray uniform steps in [near, far], mid-point evaluation, dt = step —
+                  acc_ray_marching without a grid + acc_render_volume_density (nerf_helpers_acc.py:10-63).
+    mode='dense': explicit depths z [S] or [R,S]; render_volume_density convention (nerf_helpers.py:59-123)."""
+    n_rays = ray_origins.shape[0]
+    if mode == "dense":
+        depth_samples_per_ray = z.shape[-1]
+    spec = RenderSpec(n_rays=n_rays, n_samples=int(depth_samples_per_ray), origins=ray_origins, dirs=ray_directions,
+                      mode=mode, t_near=float(near_thresh), t_far=float(far_thresh), z=z)
+    return render_spec(spec, model, want_aux)
+
+
+def render_projection(model, poses, width: int, height: int, focal: float, depth_samples_per_ray: int,
+                      near_thresh: float, far_thresh: float, ray_ids: Optional[torch.Tensor] = None,
+                      ray_id0: int = 0, n_rays: Optional[int] = None, mode: str = "acc",
+                      z: Optional[torch.Tensor] = None, want_aux: bool = False) -> RenderOutput:
+    """Pixels for rays generated in-kernel from C-arm poses (get_ray_values, phantomdata/helpers.py:156-175).
+    poses: float64 [n_proj,4,4] or [n_proj,3,4] cam->world (source_matrix); rays are indexed into
+    [n_proj, H, W] by `ray_ids` (int32) or enumerated from `ray_id0`."""
+    poses = poses[:, :3, :].contiguous()
+    if n_rays is None:
+        n_rays = ray_ids.numel() if ray_ids is not None else poses.shape[0] * width * height - ray_id0
+    if mode == "dense":
+        depth_samples_per_ray = z.shape[-1]
+    spec = RenderSpec(n_rays=int(n_rays), n_samples=int(depth_samples_per_ray), poses=poses, ray_ids=ray_ids,
+                      ray_id0=int(ray_id0), width=int(width), height=int(height), focal=float(focal), mode=mode,
+                      t_near=float(near_thresh), t_far=float(far_thresh), z=z)
+    return render_spec(spec, model, want_aux)
+
+
+def density_grid(model, outside: float, n: int) -> torch.Tensor:
+    """sigma on meshgrid(t,t,t), t = linspace(-outside, outside, n+1), numpy 'xy' indexing as upstream
+    (visualization/visualization.py:100-102,209-229): grid[i,j,k] = sigma(t[j], t[i], t[k])."""
+    _check_model(model)
+    dev = model.flat_params.device
+    t = torch.linspace(-outside, outside, n + 1, dtype=torch.float64, device=dev).float()
+    gy, gx, gz = torch.meshgrid(t, t, t, indexing="ij")      # [i,j,k] -> (x=t[j], y=t[i], z=t[k])
+    pts = torch.stack([gx, gy, gz], -1).reshape(-1, 3).contiguous()
+    with torch.no_grad():
+        sig = model.engine.infer(model._prepared(), pts, model.precision, apply_sigmoid=True)
+    return sig.reshape(n + 1, n + 1, n + 1)
