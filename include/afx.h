@@ -175,6 +175,14 @@ int afx_composite_packed_backward(const float* pred, const int32_t* ray_indices,
 int afx_fine_depths(const float* z_coarse, int z_per_ray, const float* w_coarse, const float* u,
                     int64_t n_rays, int32_t n_coarse, int32_t n_fine, float* z_out, void* stream);
 
+/* Measurement aid (bench.py's roofline leg): when enabled, every launch of the three MFMA kernels is
+ * bracketed by HIP events recorded on the launch stream.  afx_profile_read blocks on those events
+ * (the only call in this library that synchronises), returns the summed device time and the launch
+ * count for one kernel kind, and forgets them. */
+enum { AFX_K_CHAIN_FWD = 0, AFX_K_CHAIN_BWD = 1, AFX_K_WGRAD = 2 };
+int afx_profile_enable(afx_ctx* ctx, int on);
+int afx_profile_read(afx_ctx* ctx, int which, double* ms_total, int64_t* launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,6 +53,8 @@ _SIGS = {
                                        C.c_void_p]),
     "afx_composite_packed_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "afx_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "afx_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "afx_fine_depths": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                   C.c_void_p, C.c_void_p]),
 }
@@ -70,6 +72,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: it ships its own libamdhip64.so.7; libafx.so must bind to THAT runtime (the one torch's
+    # allocator and streams live in), not to a second copy pulled in through its RUNPATH.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise AfxError(f"HIP library not built: {LIB_PATH} is missing. Run `python -m nerf_for_angiography_amd.build` "
                        "(needs hipcc, --offload-arch=gfx950). There is no CPU fallback.")

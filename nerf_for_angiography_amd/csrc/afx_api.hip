@@ -4,6 +4,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string>
+#include <vector>
 #include "../../include/afx.h"
 #include "afx_internal.h"
 #include "afx_kernels_f32.hip"
@@ -26,12 +27,27 @@ static int fail(int code, const char* fmt, ...) {
     if (e_ != hipSuccess) return fail(AFX_E_HIP, "%s -> %s (%d)", #x, hipGetErrorString(e_), (int)e_); \
   } while (0)
 
+struct ProfRec { hipEvent_t a, b; int which; };
 struct afx_ctx {
   afx_model_desc d;
   int k0, nq, k0pad, nt;
   int64_t n_params;
   int n_cu;
-  bool attr_set[2];
+  bool attr_set[8];
+  bool profiling;
+  std::vector<ProfRec> recs;
+};
+
+// Optional HIP-event bracket around one kernel launch, on the launch stream (bench.py's roofline leg).
+struct ProfScope {
+  afx_ctx* c; hipStream_t st; hipEvent_t a = nullptr, b = nullptr; int which;
+  ProfScope(afx_ctx* c_, int which_, hipStream_t st_) : c(c_), st(st_), which(which_) {
+    if (c->profiling && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) (void)hipEventRecord(a, st);
+    else a = b = nullptr;
+  }
+  ~ProfScope() {
+    if (a && b) { (void)hipEventRecord(b, st); c->recs.push_back({a, b, which}); }
+  }
 };
 
 static inline uint32_t rup(uint64_t v, uint64_t a) { return (uint32_t)((v + a - 1) / a * a); }
@@ -88,12 +104,41 @@ extern "C" int afx_create(const afx_model_desc* d, afx_ctx** out) {
   c->n_cu = 256;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
     c->n_cu = prop.multiProcessorCount;
-  c->attr_set[0] = c->attr_set[1] = false;
+  for (bool& b : c->attr_set) b = false;
+  c->profiling = false;
   *out = c;
   return AFX_OK;
 }
 
-extern "C" void afx_destroy(afx_ctx* c) { delete c; }
+extern "C" void afx_destroy(afx_ctx* c) {
+  if (!c) return;
+  for (auto& r : c->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  delete c;
+}
+
+extern "C" int afx_profile_enable(afx_ctx* c, int on) {
+  if (!c) return fail(AFX_E_INVALID, "afx_profile_enable: null ctx");
+  c->profiling = on != 0;
+  return AFX_OK;
+}
+
+extern "C" int afx_profile_read(afx_ctx* c, int which, double* ms_total, int64_t* launches) {
+  if (!c || !ms_total || !launches) return fail(AFX_E_INVALID, "afx_profile_read: null argument");
+  double tot = 0.0;
+  int64_t n = 0;
+  std::vector<ProfRec> keep;
+  for (auto& r : c->recs) {
+    if (r.which != which) { keep.push_back(r); continue; }
+    HIPCHK(hipEventSynchronize(r.b));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
+    tot += ms; ++n;
+    (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+  }
+  c->recs.swap(keep);
+  *ms_total = tot; *launches = n;
+  return AFX_OK;
+}
 
 extern "C" int afx_param_layout(const afx_ctx* c, int layer, int64_t* w_off, int64_t* b_off, int32_t* rows, int32_t* cols) {
   if (!c) return fail(AFX_E_INVALID, "afx_param_layout: null ctx");
@@ -178,7 +223,10 @@ static int launch_chain_t(afx_ctx* c, const ChainArgs& a, size_t lds_bytes, int 
     HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     c->attr_set[BWD ? 1 : 0] = true;
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, st, a);
+  {
+    ProfScope ps(c, BWD ? AFX_K_CHAIN_BWD : AFX_K_CHAIN_FWD, st);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, st, a);
+  }
   HIPCHK(hipGetLastError());
   return AFX_OK;
 }
@@ -256,6 +304,7 @@ static void fill_render(const afx_render_args* r, ChainArgs& a) {
 }
 
 extern "C" int afx_render_forward(afx_ctx* c, int prec, const void* prepared, const afx_render_args* r, void* stream) {
+  if (c && r && r->n_rays == 0) return AFX_OK;
   int rc = check_render(c, r, "afx_render_forward");
   if (rc) return rc;
   if (prec != AFX_PREC_F32) return fail(AFX_E_INVALID, "afx_render_forward: precision %d not built", prec);
@@ -277,9 +326,17 @@ extern "C" int afx_render_forward(afx_ctx* c, int prec, const void* prepared, co
 }
 
 template <int F>
-static int launch_wgrad_t(const WgradArgs& w, const ReduceArgs& rd, int N, hipStream_t st) {
-  hipLaunchKernelGGL(k_wgrad_f32<F>, dim3(w.n_splits, N + 1), dim3(512), 0, st, w);
-  hipLaunchKernelGGL(k_colsum_f32<F>, dim3(w.n_splits, N + 2), dim3(F), 0, st, w);
+static int launch_wgrad_t(afx_ctx* c, const WgradArgs& w, const ReduceArgs& rd, int N, hipStream_t st) {
+  {
+    const size_t lds = (size_t)2 * 2 * 32 * F * 4;      // 2 stages x (A + B chunk of 32 samples)
+    if (!c->attr_set[2]) {
+      HIPCHK(hipFuncSetAttribute((const void*)k_wgrad_f32<F>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      c->attr_set[2] = true;
+    }
+    ProfScope ps(c, AFX_K_WGRAD, st);
+    hipLaunchKernelGGL(k_wgrad_f32<F>, dim3(w.n_splits, N + 1), dim3(512), lds, st, w);
+  }
+  hipLaunchKernelGGL(k_colsum_f32<F>, dim3(w.n_splits, N + 2), dim3(1024), 0, st, w);
   hipLaunchKernelGGL(k_reduce_w<F>, dim3((F * F + 255) / 256, N + 1), dim3(256), 0, st, rd);
   hipLaunchKernelGGL(k_reduce_b<F>, dim3(1, N + 2), dim3(F), 0, st, rd);
   HIPCHK(hipGetLastError());
@@ -316,20 +373,22 @@ static int run_backward(afx_ctx* c, ChainArgs a, size_t head, char* ws, size_t w
     w.rows = (t1 - t0) * TILE;
     w.stride_rows = (int64_t)rows;   // a short last chunk keeps the full-chunk layer stride
     w.n_hidden = N; w.k0 = c->k0; w.k0pad = c->k0pad;
-    int splits = (int)(w.rows / 256);
+    // (splits x (N+1)) workgroups of 8 waves, one per CU at a time: fill the chip in whole rounds
+    int splits = (2 * c->n_cu) / (N + 1);
+    if (splits > (int)(w.rows / 256)) splits = (int)(w.rows / 256);
     if (splits < 1) splits = 1;
     if (splits > kSplits) splits = kSplits;
     w.n_splits = splits;
     int64_t rps = (w.rows + splits - 1) / splits;
-    rps = (rps + 1) / 2 * 2;
+    rps = (rps + 31) / 32 * 32;        // whole 32-sample stages
     w.rows_per_split = (int)rps;
     w.partial = partial; w.partial2 = partial2;
     ReduceArgs rd;
     rd.partial = partial; rd.partial2 = partial2; rd.n_hidden = N; rd.k0 = c->k0; rd.k0pad = c->k0pad; rd.n_splits = splits;
     rd.grad = grad_flat;
-    if (F == 64) rc = launch_wgrad_t<64>(w, rd, N, st);
-    else if (F == 128) rc = launch_wgrad_t<128>(w, rd, N, st);
-    else rc = launch_wgrad_t<256>(w, rd, N, st);
+    if (F == 64) rc = launch_wgrad_t<64>(c, w, rd, N, st);
+    else if (F == 128) rc = launch_wgrad_t<128>(c, w, rd, N, st);
+    else rc = launch_wgrad_t<256>(c, w, rd, N, st);
     if (rc) return rc;
   }
   return AFX_OK;
@@ -337,6 +396,7 @@ static int run_backward(afx_ctx* c, ChainArgs a, size_t head, char* ws, size_t w
 
 extern "C" int afx_render_backward(afx_ctx* c, int prec, const void* prepared, const afx_render_args* r,
                                    const float* dL_dpixel, float* grad_flat, void* stream) {
+  if (c && r && r->n_rays == 0) return AFX_OK;
   int rc = check_render(c, r, "afx_render_backward");
   if (rc) return rc;
   if (prec != AFX_PREC_F32) return fail(AFX_E_INVALID, "afx_render_backward: precision %d not built", prec);

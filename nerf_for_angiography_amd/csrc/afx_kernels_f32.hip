@@ -371,12 +371,19 @@ __global__ void __launch_bounds__(256, 1) k_chain_f32(const ChainArgs a) {
 // Weight gradients: dW_l[o][i] = sum_n dZ_l[n][o] * H_{l-1}[n][i]  (layer 0: B = encoded inputs).
 // Contraction over samples, split over blockIdx.x; each split writes a partial that
 // k_reduce sums in fixed order (deterministic).  grid = (n_splits, N+1), block = 512.
+// 32-sample chunks of both stashes are staged in LDS by LDS-DMA (double-buffered); the MFMA
+// operands (A[i][k] = dZ[n+k][o0+i], B[k][j] = H[n+k][i0+j], k = lane>>5) are conflict-free
+// ds_read_b32 (consecutive lanes -> consecutive features).
 // ---------------------------------------------------------------------------------------
 template <int F>
 __global__ void __launch_bounds__(512) k_wgrad_f32(const WgradArgs a) {
   constexpr int NT = F / 32;
   constexpr int TPW = (NT * NT + 7) / 8;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, hh = lane >> 5;
+  constexpr int KB = 32;                      // samples per stage
+  constexpr int STAGE = 2 * KB * F;           // floats per stage: A chunk then B chunk
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  float* lds = (float*)lds_raw;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, hh = lane >> 5;
   const int layer = blockIdx.y, split = blockIdx.x;
   const float* A = a.stash_dz + (size_t)layer * a.stride_rows * F;
   const float* B;
@@ -387,6 +394,7 @@ __global__ void __launch_bounds__(512) k_wgrad_f32(const WgradArgs a) {
   int64_t r0 = (int64_t)split * a.rows_per_split;
   int64_t r1 = r0 + a.rows_per_split;
   if (r1 > a.rows) r1 = a.rows;
+  const int nst = r1 > r0 ? (int)((r1 - r0) / KB) : 0;
 
   f32x16 acc[TPW];
   int to[TPW], ti[TPW];
@@ -399,15 +407,38 @@ __global__ void __launch_bounds__(512) k_wgrad_f32(const WgradArgs a) {
     to[mm] = ok[mm] ? idx / ntb : 0;
     ti[mm] = ok[mm] ? idx % ntb : 0;
   }
-#pragma unroll 2
-  for (int64_t nn = r0; nn < r1; nn += 2) {
+  auto stage_load = [&](int st, int buf) {
+    float* dA = lds + buf * STAGE;
+    float* dB = dA + KB * F;
+    const char* gA = (const char*)(A + (r0 + (int64_t)st * KB) * F);
+    for (int off = wave * 1024; off < KB * F * 4; off += 8192)
+      __builtin_amdgcn_global_load_lds(GPTR(gA + off + lane * 16), LPTR((char*)dA + off), 16, 0, 0);
+    if (layer != 0) {
+      const char* gB = (const char*)(B + (r0 + (int64_t)st * KB) * F);
+      for (int off = wave * 1024; off < KB * F * 4; off += 8192)
+        __builtin_amdgcn_global_load_lds(GPTR(gB + off + lane * 16), LPTR((char*)dB + off), 16, 0, 0);
+    } else {
+      const float* gB = B + (r0 + (int64_t)st * KB) * ldb;
+      for (int i = tid; i < KB * ldb; i += 512) dB[i] = gB[i];
+    }
+  };
+  if (nst > 0) stage_load(0, 0);
+  for (int st = 0; st < nst; ++st) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (st + 1 < nst) stage_load(st + 1, (st + 1) & 1);
+    const float* sA = lds + (st & 1) * STAGE;
+    const float* sB = sA + KB * F;
+#pragma unroll 4
+    for (int k = 0; k < KB; k += 2) {
 #pragma unroll
-    for (int mm = 0; mm < TPW; ++mm) {
-      if (ok[mm]) {
-        const float av = A[(nn + hh) * F + 32 * to[mm] + col];
-        const int cb = 32 * ti[mm] + col;
-        const float bv = cb < ncols ? B[(nn + hh) * ldb + cb] : 0.f;
-        acc[mm] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mm], 0, 0, 0);
+      for (int mm = 0; mm < TPW; ++mm) {
+        if (ok[mm]) {
+          const float av = sA[(k + hh) * F + 32 * to[mm] + col];
+          const int cb = 32 * ti[mm] + col;
+          const float bv = cb < ncols ? sB[(k + hh) * ldb + cb] : 0.f;
+          acc[mm] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mm], 0, 0, 0);
+        }
       }
     }
   }
@@ -426,27 +457,36 @@ __global__ void __launch_bounds__(512) k_wgrad_f32(const WgradArgs a) {
 // (y = N+1: sum_n graw[n] * H_N[n][f], plus sum_n graw[n] in slot F).  grid = (n_splits, N+2),
 // block = F threads.
 template <int F>
-__global__ void k_colsum_f32(const WgradArgs a) {
-  const int f = threadIdx.x, y = blockIdx.y, split = blockIdx.x;
+__global__ void __launch_bounds__(1024) k_colsum_f32(const WgradArgs a) {
+  constexpr int G = 1024 / F;                 // row groups per block
+  __shared__ float red[1024 + 32];
+  const int f = threadIdx.x % F, gq = threadIdx.x / F, y = blockIdx.y, split = blockIdx.x;
   int64_t r0 = (int64_t)split * a.rows_per_split;
   int64_t r1 = r0 + a.rows_per_split;
   if (r1 > a.rows) r1 = a.rows;
-  float* P = a.partial2 + ((size_t)y * a.n_splits + split) * (F + 4);
+  float s = 0.f, sg = 0.f;
   if (y <= a.n_hidden) {
     const float* X = a.stash_dz + (size_t)y * a.stride_rows * F;
-    float s = 0.f;
-    for (int64_t r = r0; r < r1; ++r) s += X[r * F + f];
-    P[f] = s;
+#pragma unroll 8
+    for (int64_t r = r0 + gq; r < r1; r += G) s += X[r * F + f];
   } else {
     const float* X = a.stash_h + (size_t)a.n_hidden * a.stride_rows * F;
-    float s = 0.f, sg = 0.f;
-    for (int64_t r = r0; r < r1; ++r) {
+#pragma unroll 8
+    for (int64_t r = r0 + gq; r < r1; r += G) {
       const float g = a.graw[r];
       s = fmaf(g, X[r * F + f], s);
       sg += g;
     }
-    P[f] = s;
-    if (f == 0) P[F] = sg;
+  }
+  red[threadIdx.x] = s;
+  if (f == 0) red[1024 + gq] = sg;
+  __syncthreads();
+  if (gq == 0) {
+    float t = 0.f, tg = 0.f;
+    for (int q = 0; q < G; ++q) { t += red[q * F + f]; if (f == 0) tg += red[1024 + q]; }
+    float* P = a.partial2 + ((size_t)y * a.n_splits + split) * (F + 4);
+    P[f] = t;
+    if (y == a.n_hidden + 1 && f == 0) P[F] = tg;
   }
 }
 

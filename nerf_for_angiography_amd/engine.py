@@ -76,6 +76,18 @@ class Engine:
         except Exception:
             pass
 
+    # ---- measurement ---------------------------------------------------------------------------
+    KERNELS = {"chain_fwd": 0, "chain_bwd": 1, "wgrad": 2}
+
+    def profile(self, on: bool):
+        _lib.check(self.lib.afx_profile_enable(self.h, int(on)), "afx_profile_enable")
+
+    def profile_read(self, kernel: str):
+        """(total device ms, launches) of one kernel kind since the last read (HIP events on the launch stream)."""
+        ms, n = C.c_double(), C.c_int64()
+        _lib.check(self.lib.afx_profile_read(self.h, self.KERNELS[kernel], C.byref(ms), C.byref(n)), "afx_profile_read")
+        return ms.value, n.value
+
     # ---- parameter layout ------------------------------------------------------------------
     def layout(self, layer: int):
         wo, bo, r, c = C.c_int64(), C.c_int64(), C.c_int32(), C.c_int32()
