@@ -8,6 +8,8 @@
 #include "../../include/afx.h"
 #include "afx_internal.h"
 #include "afx_kernels_f32.hip"
+#include "afx_kernels_bf16.hip"
+#include <set>
 
 using namespace afx;
 
@@ -33,7 +35,7 @@ struct afx_ctx {
   int k0, nq, k0pad, nt;
   int64_t n_params;
   int n_cu;
-  bool attr_set[8];
+  std::set<const void*> attr_done;
   bool profiling;
   std::vector<ProfRec> recs;
 };
@@ -55,26 +57,40 @@ static inline size_t rup64(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // Layout of the prepared-weights buffer for one precision.
 struct PrepLayout {
-  uint32_t small_floats, small_bytes_pad, slab0_bytes, slabh_bytes, slot_bytes;
+  uint32_t small_floats, small_bytes_pad, slab0_bytes, slabh_stride, slabt_bytes;
   uint32_t small_off, slab0_off, fwd_off, bwd_off;
+  int n_slab0;          // slabs of the first layer in the forward stream (1 for f32, NT for bf16)
   size_t total;
 };
 
+static inline bool is_bf16(int prec) { return prec == AFX_PREC_BF16 || prec == AFX_PREC_BF16X3; }
+static inline int nk0_of(const afx_ctx* c) { return c->d.enc == AFX_ENC_NONE ? 1 : 4; }
+// samples per workgroup tile of the forward / backward chain kernel
+static inline int fwd_tile(int prec) { return prec == AFX_PREC_BF16 ? 256 : 128; }
+static inline int bwd_tile(int prec) { return prec == AFX_PREC_F32 ? 128 : 256; }
+
 static PrepLayout prep_layout(const afx_ctx* c, int prec) {
-  (void)prec;
   PrepLayout L;
   const int F = c->d.width, N = c->d.n_hidden, NT = c->nt;
   const int naux = c->d.enc == AFX_ENC_BARF ? 6 * c->d.n_freq : (c->d.enc == AFX_ENC_FOURIER ? 3 * c->d.n_freq : 0);
   L.small_floats = rup((uint64_t)(N + 2) * F + 4 + naux, 4);
   L.small_bytes_pad = rup((uint64_t)L.small_floats * 4, 1024);
-  L.slab0_bytes = rup((uint64_t)c->nq * NT * 256, 4096);
-  L.slabh_bytes = (uint32_t)NT * 4 * 1024;
-  L.slot_bytes = L.slab0_bytes > L.slabh_bytes ? L.slab0_bytes : L.slabh_bytes;
   L.small_off = 0;
   L.slab0_off = rup((uint64_t)L.small_floats * 4, 4096);
-  L.fwd_off = L.slab0_off + L.slab0_bytes;          // contiguous with slab0: one forward stream
-  L.bwd_off = L.fwd_off + (uint32_t)N * NT * L.slabh_bytes;
-  L.total = (size_t)L.bwd_off + (size_t)N * NT * L.slabh_bytes;
+  if (prec == AFX_PREC_F32) {
+    L.n_slab0 = 1;
+    L.slab0_bytes = rup((uint64_t)c->nq * NT * 256, 4096);
+    L.slabh_stride = (uint32_t)NT * 4 * 1024;
+    L.slabt_bytes = L.slabh_stride;
+  } else {
+    L.n_slab0 = NT;
+    L.slab0_bytes = rup((uint64_t)nk0_of(c) * 2 * 1024, 4096);
+    L.slabt_bytes = (uint32_t)NT * 2 * 1024;
+    L.slabh_stride = (prec == AFX_PREC_BF16X3 ? 2u : 1u) * L.slabt_bytes;
+  }
+  L.fwd_off = L.slab0_off + (uint32_t)L.n_slab0 * L.slab0_bytes;   // contiguous: one forward stream
+  L.bwd_off = L.fwd_off + (uint32_t)N * NT * L.slabh_stride;
+  L.total = (size_t)L.bwd_off + (size_t)N * NT * L.slabt_bytes;
   return L;
 }
 
@@ -104,7 +120,6 @@ extern "C" int afx_create(const afx_model_desc* d, afx_ctx** out) {
   c->n_cu = 256;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
     c->n_cu = prop.multiProcessorCount;
-  for (bool& b : c->attr_set) b = false;
   c->profiling = false;
   *out = c;
   return AFX_OK;
@@ -159,18 +174,18 @@ extern "C" int afx_param_layout(const afx_ctx* c, int layer, int64_t* w_off, int
 
 // Backward workspace: fixed part + per-tile part.
 struct BwdLayout {
-  size_t dod_off, fixed_bytes, per_tile_bytes;
+  size_t fixed_bytes, per_tile_bytes;
 };
 static const int kSplits = 64;
-static BwdLayout bwd_layout(const afx_ctx* c, int64_t n_rays) {
+static BwdLayout bwd_layout(const afx_ctx* c, int prec, int64_t n_rays) {
   const size_t F = c->d.width, N = c->d.n_hidden;
   BwdLayout B;
-  B.dod_off = 0;
   size_t fixed = rup64((size_t)n_rays * 4, 256);   // dod (rays mode only)
   fixed += rup64((N + 1) * (size_t)kSplits * F * F * 4, 256);     // partial
   fixed += rup64((N + 2) * (size_t)kSplits * (F + 4) * 4, 256);   // partial2
   B.fixed_bytes = fixed;
-  B.per_tile_bytes = (size_t)TILE * 4 * (2 * (N + 1) * F + c->k0pad + 1);
+  if (prec == AFX_PREC_F32) B.per_tile_bytes = (size_t)128 * 4 * (2 * (N + 1) * F + c->k0pad + 1);
+  else B.per_tile_bytes = (size_t)256 * (2 * (N + 1) * F * 2 + 4 * 16 * nk0_of(c) + 4);
   return B;
 }
 
@@ -184,25 +199,29 @@ extern "C" int64_t afx_query(const afx_ctx* c, int what, int64_t a0, int64_t a1,
     case AFX_Q_PREPARED_BYTES: return (int64_t)prep_layout(c, (int)a0).total;
     case AFX_Q_FWD_WORKSPACE: return (int64_t)rup64((size_t)a0 * (size_t)(s_pad_of((int)a1) / GROUP) * 4, 256);
     case AFX_Q_BWD_WORKSPACE_MIN: {
-      BwdLayout B = bwd_layout(c, a0);
+      BwdLayout B = bwd_layout(c, (int)a2, a0);
       return (int64_t)(B.fixed_bytes + 32 * B.per_tile_bytes);
     }
     case AFX_Q_BWD_WORKSPACE_FULL: {
-      BwdLayout B = bwd_layout(c, a0);
+      BwdLayout B = bwd_layout(c, (int)a2, a0);
       const int64_t samples = a0 > 0 ? a0 * s_pad_of((int)a1) : a1;
-      const int64_t tiles = (samples + TILE - 1) / TILE;
+      const int64_t tiles = (samples + bwd_tile((int)a2) - 1) / bwd_tile((int)a2);
       return (int64_t)(B.fixed_bytes + (size_t)tiles * B.per_tile_bytes);
     }
   }
   fail(AFX_E_INVALID, "afx_query: unknown query %d", what);
-  (void)a2;
   return -1;
+}
+
+static int check_prec(int prec, const char* who) {
+  if (prec != AFX_PREC_F32 && prec != AFX_PREC_BF16X3 && prec != AFX_PREC_BF16) return fail(AFX_E_INVALID, "%s: unknown precision %d", who, prec);
+  return AFX_OK;
 }
 
 extern "C" int afx_prepare_weights(afx_ctx* c, int prec, const float* params, const float* enc_aux, void* prepared,
                                    size_t prepared_bytes, void* stream) {
   if (!c || !params || !prepared) return fail(AFX_E_INVALID, "afx_prepare_weights: null argument");
-  if (prec != AFX_PREC_F32) return fail(AFX_E_INVALID, "afx_prepare_weights: precision %d not built", prec);
+  if (check_prec(prec, "afx_prepare_weights")) return AFX_E_INVALID;
   if (c->d.enc != AFX_ENC_NONE && !enc_aux) return fail(AFX_E_INVALID, "afx_prepare_weights: enc_aux required for this encoding");
   const PrepLayout L = prep_layout(c, prec);
   if (prepared_bytes < L.total) return fail(AFX_E_WORKSPACE, "afx_prepare_weights: prepared buffer %zu < %zu bytes", prepared_bytes, L.total);
@@ -210,64 +229,92 @@ extern "C" int afx_prepare_weights(afx_ctx* c, int prec, const float* params, co
   p.params = params; p.enc_aux = enc_aux; p.prepared = (char*)prepared;
   p.F = c->d.width; p.n_hidden = c->d.n_hidden; p.k0 = c->k0; p.nq = c->nq; p.enc = c->d.enc; p.n_freq = c->d.n_freq;
   p.small_off = L.small_off; p.slab0_off = L.slab0_off; p.fwd_off = L.fwd_off; p.bwd_off = L.bwd_off;
-  p.slab0_bytes = L.slab0_bytes; p.slabh_bytes = L.slabh_bytes; p.small_floats = L.small_floats;
+  p.slab0_bytes = L.slab0_bytes; p.slabh_bytes = L.slabh_stride; p.small_floats = L.small_floats;
+  p.weights = prec == AFX_PREC_F32 ? 1 : 0;
   hipLaunchKernelGGL(k_prepare_f32, dim3(512), dim3(256), 0, (hipStream_t)stream, p);
+  if (is_bf16(prec)) {
+    PrepArgs16 q;
+    q.params = params; q.prepared = (char*)prepared;
+    q.F = c->d.width; q.n_hidden = c->d.n_hidden; q.k0 = c->k0; q.nk0 = nk0_of(c); q.parts = prec == AFX_PREC_BF16X3 ? 2 : 1;
+    q.slab0_off = L.slab0_off; q.slab0_bytes = L.slab0_bytes; q.fwd_off = L.fwd_off; q.slabh_stride = L.slabh_stride;
+    q.bwd_off = L.bwd_off; q.slabt_bytes = L.slabt_bytes;
+    hipLaunchKernelGGL(k_prepare_bf16, dim3(512), dim3(256), 0, (hipStream_t)stream, q);
+  }
   HIPCHK(hipGetLastError());
   return AFX_OK;
 }
 
-template <int F, bool BWD>
-static int launch_chain_t(afx_ctx* c, const ChainArgs& a, size_t lds_bytes, int grid, hipStream_t st) {
-  auto kern = k_chain_f32<F, BWD>;
-  if (!c->attr_set[BWD ? 1 : 0]) {
+template <class K>
+static int launch_chain_k(afx_ctx* c, K kern, int which, const ChainArgs& a, size_t lds_bytes, int grid, hipStream_t st) {
+  if (!c->attr_done.count((const void*)kern)) {
     HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    c->attr_set[BWD ? 1 : 0] = true;
+    c->attr_done.insert((const void*)kern);
   }
   {
-    ProfScope ps(c, BWD ? AFX_K_CHAIN_BWD : AFX_K_CHAIN_FWD, st);
+    ProfScope ps(c, which, st);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, st, a);
   }
   HIPCHK(hipGetLastError());
   return AFX_OK;
 }
 
-static int launch_chain(afx_ctx* c, bool bwd, const ChainArgs& a, hipStream_t st) {
+template <int F>
+static int launch_chain_f(afx_ctx* c, int prec, bool bwd, const ChainArgs& a, size_t lds, int grid, hipStream_t st) {
+  const int which = bwd ? AFX_K_CHAIN_BWD : AFX_K_CHAIN_FWD;
+  const bool enc = c->d.enc != AFX_ENC_NONE;
+  if (prec == AFX_PREC_F32)
+    return bwd ? launch_chain_k(c, k_chain_f32<F, true>, which, a, lds, grid, st) : launch_chain_k(c, k_chain_f32<F, false>, which, a, lds, grid, st);
+  if (bwd)
+    return enc ? launch_chain_k(c, k_chain_bf16<F, false, true, true>, which, a, lds, grid, st)
+               : launch_chain_k(c, k_chain_bf16<F, false, false, true>, which, a, lds, grid, st);
+  if (prec == AFX_PREC_BF16X3)
+    return enc ? launch_chain_k(c, k_chain_bf16<F, true, true, false>, which, a, lds, grid, st)
+               : launch_chain_k(c, k_chain_bf16<F, true, false, false>, which, a, lds, grid, st);
+  return enc ? launch_chain_k(c, k_chain_bf16<F, false, true, false>, which, a, lds, grid, st)
+             : launch_chain_k(c, k_chain_bf16<F, false, false, false>, which, a, lds, grid, st);
+}
+
+static int launch_chain(afx_ctx* c, int prec, bool bwd, const ChainArgs& a, hipStream_t st) {
   const int F = c->d.width, N = c->d.n_hidden;
   size_t lds = (size_t)a.small_bytes_pad + 2 * (size_t)a.slot_bytes;
-  if (bwd) lds += (size_t)(N + 1) * ((c->nt + 1) / 2) * 256 * 4;
+  const int ncg = (is_bf16(prec) && (bwd || prec == AFX_PREC_BF16)) ? 2 : 1;
+  if (bwd) lds += (size_t)(N + 1) * ((c->nt + 1) / 2) * ncg * 256 * 4;
   if (lds > 160 * 1024) return fail(AFX_E_INVALID, "model needs %zu B of LDS (> 160 KiB)", lds);
   const int tiles = a.tile1 - a.tile0;
   if (tiles <= 0) return AFX_OK;
   const int grid = tiles < c->n_cu ? tiles : c->n_cu;
-  if (F == 64) return bwd ? launch_chain_t<64, true>(c, a, lds, grid, st) : launch_chain_t<64, false>(c, a, lds, grid, st);
-  if (F == 128) return bwd ? launch_chain_t<128, true>(c, a, lds, grid, st) : launch_chain_t<128, false>(c, a, lds, grid, st);
-  return bwd ? launch_chain_t<256, true>(c, a, lds, grid, st) : launch_chain_t<256, false>(c, a, lds, grid, st);
+  if (F == 64) return launch_chain_f<64>(c, prec, bwd, a, lds, grid, st);
+  if (F == 128) return launch_chain_f<128>(c, prec, bwd, a, lds, grid, st);
+  return launch_chain_f<256>(c, prec, bwd, a, lds, grid, st);
 }
 
-static void fill_model(const afx_ctx* c, int prec, const void* prepared, ChainArgs& a) {
+static void fill_model(const afx_ctx* c, int prec, bool bwd, const void* prepared, ChainArgs& a) {
   const PrepLayout L = prep_layout(c, prec);
   const char* base = (const char*)prepared;
   a.stream_fwd = base + L.slab0_off;
   a.stream_bwd = base + L.bwd_off;
   a.small = (const float*)(base + L.small_off);
   a.small_floats = L.small_floats; a.small_bytes_pad = L.small_bytes_pad;
-  a.slab0_bytes = L.slab0_bytes; a.slabh_bytes = L.slabh_bytes; a.slot_bytes = L.slot_bytes;
+  a.slab0_bytes = L.slab0_bytes; a.slabh_stride = L.slabh_stride; a.slabt_bytes = L.slabt_bytes;
+  // the backward kernel of the split mode recomputes in plain bf16: it streams only the hi halves
+  a.slabh_bytes = (prec == AFX_PREC_BF16X3 && bwd) ? L.slabt_bytes : L.slabh_stride;
+  a.slot_bytes = a.slab0_bytes > a.slabh_bytes ? a.slab0_bytes : a.slabh_bytes;
   a.n_hidden = c->d.n_hidden; a.k0 = c->k0; a.nq = c->nq; a.enc = c->d.enc; a.n_freq = c->d.n_freq;
 }
 
 extern "C" int afx_mlp_infer(afx_ctx* c, int prec, const void* prepared, const float* pts, int64_t n_pts, float* out,
                              int apply_sigmoid, void* stream) {
   if (!c || !prepared || !pts || !out) return fail(AFX_E_INVALID, "afx_mlp_infer: null argument");
-  if (prec != AFX_PREC_F32) return fail(AFX_E_INVALID, "afx_mlp_infer: precision %d not built", prec);
+  if (check_prec(prec, "afx_mlp_infer")) return AFX_E_INVALID;
   if (n_pts < 0 || n_pts > (int64_t)1 << 37) return fail(AFX_E_INVALID, "afx_mlp_infer: bad n_pts");
   if (n_pts == 0) return AFX_OK;
   ChainArgs a = {};
-  fill_model(c, prec, prepared, a);
-  const int64_t tiles = (n_pts + TILE - 1) / TILE;
+  fill_model(c, prec, false, prepared, a);
+  const int64_t tiles = (n_pts + fwd_tile(prec) - 1) / fwd_tile(prec);
   if (tiles > 0x7fffffff) return fail(AFX_E_INVALID, "afx_mlp_infer: too many points for one call");
   a.tile0 = 0; a.tile1 = (int)tiles; a.n_total = n_pts; a.mode = 0;
   a.pts = pts; a.out = out; a.apply_sigmoid = apply_sigmoid;
-  return launch_chain(c, false, a, (hipStream_t)stream);
+  return launch_chain(c, prec, false, a, (hipStream_t)stream);
 }
 
 static int check_render(const afx_ctx* c, const afx_render_args* r, const char* who) {
@@ -285,7 +332,7 @@ static int check_render(const afx_ctx* c, const afx_render_args* r, const char* 
     if (!r->z) return fail(AFX_E_INVALID, "%s: z required for this depth_mode", who);
   } else return fail(AFX_E_INVALID, "%s: bad depth_mode %d", who, r->depth_mode);
   if (!r->pixel) return fail(AFX_E_INVALID, "%s: pixel required", who);
-  if (r->n_rays * s_pad_of(r->n_samples) > ((int64_t)1 << 31) - TILE)
+  if (r->n_rays * s_pad_of(r->n_samples) > ((int64_t)1 << 31) - 256)
     return fail(AFX_E_INVALID, "%s: n_rays*padded samples must be < 2^31 per call; split the ray batch", who);
   return AFX_OK;
 }
@@ -307,18 +354,18 @@ extern "C" int afx_render_forward(afx_ctx* c, int prec, const void* prepared, co
   if (c && r && r->n_rays == 0) return AFX_OK;
   int rc = check_render(c, r, "afx_render_forward");
   if (rc) return rc;
-  if (prec != AFX_PREC_F32) return fail(AFX_E_INVALID, "afx_render_forward: precision %d not built", prec);
+  if (check_prec(prec, "afx_render_forward")) return AFX_E_INVALID;
   if (!prepared) return fail(AFX_E_INVALID, "afx_render_forward: null prepared");
   if (r->n_rays == 0) return AFX_OK;
   const size_t need = (size_t)afx_query(c, AFX_Q_FWD_WORKSPACE, r->n_rays, r->n_samples, 0);
   if (!r->workspace || r->workspace_bytes < need) return fail(AFX_E_WORKSPACE, "afx_render_forward: workspace %zu < %zu bytes", r->workspace_bytes, need);
   hipStream_t st = (hipStream_t)stream;
   ChainArgs a = {};
-  fill_model(c, prec, prepared, a);
+  fill_model(c, prec, false, prepared, a);
   fill_render(r, a);
   a.od_part = (float*)r->workspace;
-  a.tile0 = 0; a.tile1 = (int)((a.n_total + TILE - 1) / TILE);
-  rc = launch_chain(c, false, a, st);
+  a.tile0 = 0; a.tile1 = (int)((a.n_total + fwd_tile(prec) - 1) / fwd_tile(prec));
+  rc = launch_chain(c, prec, false, a, st);
   if (rc) return rc;
   hipLaunchKernelGGL(k_finish_fwd, dim3((unsigned)((r->n_rays + 255) / 256)), dim3(256), 0, st, a.od_part, a.s_pad / GROUP, r->n_rays, r->pixel);
   HIPCHK(hipGetLastError());
@@ -329,9 +376,9 @@ template <int F>
 static int launch_wgrad_t(afx_ctx* c, const WgradArgs& w, const ReduceArgs& rd, int N, hipStream_t st) {
   {
     const size_t lds = (size_t)2 * 2 * 32 * F * 4;      // 2 stages x (A + B chunk of 32 samples)
-    if (!c->attr_set[2]) {
+    if (!c->attr_done.count((const void*)k_wgrad_f32<F>)) {
       HIPCHK(hipFuncSetAttribute((const void*)k_wgrad_f32<F>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      c->attr_set[2] = true;
+      c->attr_done.insert((const void*)k_wgrad_f32<F>);
     }
     ProfScope ps(c, AFX_K_WGRAD, st);
     hipLaunchKernelGGL(k_wgrad_f32<F>, dim3(w.n_splits, N + 1), dim3(512), lds, st, w);
@@ -343,13 +390,36 @@ static int launch_wgrad_t(afx_ctx* c, const WgradArgs& w, const ReduceArgs& rd, 
   return AFX_OK;
 }
 
+template <int F>
+static int launch_wgrad16_t(afx_ctx* c, const WgradArgs& w, const ReduceArgs& rd, int N, hipStream_t st) {
+  {
+    const size_t lds = (size_t)4 * 64 * 2 * F;          // 2 stages x (dZ + H image of 64 samples)
+    if (!c->attr_done.count((const void*)k_wgrad_bf16<F>)) {
+      HIPCHK(hipFuncSetAttribute((const void*)k_wgrad_bf16<F>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      c->attr_done.insert((const void*)k_wgrad_bf16<F>);
+    }
+    ProfScope ps(c, AFX_K_WGRAD, st);
+    hipLaunchKernelGGL(k_wgrad_bf16<F>, dim3(w.n_splits, N), dim3(512), lds, st, w);
+  }
+  if (c->d.enc != AFX_ENC_NONE) hipLaunchKernelGGL((k_small_grads_bf16<F, true>), dim3(w.n_splits, 2), dim3(F), 0, st, w);
+  else hipLaunchKernelGGL((k_small_grads_bf16<F, false>), dim3(w.n_splits, 2), dim3(F), 0, st, w);
+  hipLaunchKernelGGL(k_reduce_w<F>, dim3((F * F + 255) / 256, N + 1), dim3(256), 0, st, rd);
+  hipLaunchKernelGGL(k_reduce_b<F>, dim3(1, N + 2), dim3(F), 0, st, rd);
+  HIPCHK(hipGetLastError());
+  return AFX_OK;
+}
+
 // Shared by afx_render_backward / afx_mlp_backward: chain (recompute + input-gradient chain +
 // stash) then the weight-gradient contraction, chunk by chunk.  `a` is fully filled except the
 // backward pointers; `head` bytes at the start of the workspace are already in use (dod).
-static int run_backward(afx_ctx* c, ChainArgs a, size_t head, char* ws, size_t ws_bytes, float* grad_flat, hipStream_t st) {
+static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws, size_t ws_bytes, float* grad_flat, hipStream_t st) {
   const int F = c->d.width, N = c->d.n_hidden;
-  const BwdLayout B = bwd_layout(c, 0);
+  const BwdLayout B = bwd_layout(c, prec, 0);
   const size_t fixed = head + B.fixed_bytes;
+  const int TILE = bwd_tile(prec);
+  const bool b16 = is_bf16(prec);
+  const size_t esz = b16 ? 2 : 4;                       // stash element size
+  const int k0ld = b16 ? 16 * nk0_of(c) : c->k0pad;     // row length of the encoded-input stash
   if (ws_bytes < fixed + B.per_tile_bytes) return fail(AFX_E_WORKSPACE, "backward workspace %zu too small (min %zu)", ws_bytes, fixed + 32 * B.per_tile_bytes);
   const int64_t tiles = (a.n_total + TILE - 1) / TILE;
   int64_t chunk = (int64_t)((ws_bytes - fixed) / B.per_tile_bytes);
@@ -358,37 +428,37 @@ static int run_backward(afx_ctx* c, ChainArgs a, size_t head, char* ws, size_t w
   float* partial = (float*)(ws + off); off += rup64((size_t)(N + 1) * kSplits * F * F * 4, 256);
   float* partial2 = (float*)(ws + off); off += rup64((size_t)(N + 2) * kSplits * (F + 4) * 4, 256);
   const size_t rows = (size_t)chunk * TILE;
-  a.stash_h = (float*)(ws + off); off += (size_t)(N + 1) * rows * F * 4;
-  a.stash_dz = (float*)(ws + off); off += (size_t)(N + 1) * rows * F * 4;
-  a.stash_e = (float*)(ws + off); off += rows * c->k0pad * 4;
+  a.stash_h = (float*)(ws + off); off += (size_t)(N + 1) * rows * F * esz;
+  a.stash_dz = (float*)(ws + off); off += (size_t)(N + 1) * rows * F * esz;
+  a.stash_e = (float*)(ws + off); off += rows * k0ld * 4;
   a.graw = (float*)(ws + off);
   a.stash_rows = (int64_t)rows;
   for (int64_t t0 = 0; t0 < tiles; t0 += chunk) {
     const int64_t t1 = t0 + chunk < tiles ? t0 + chunk : tiles;
     a.tile0 = (int)t0; a.tile1 = (int)t1;
-    int rc = launch_chain(c, true, a, st);
+    int rc = launch_chain(c, prec, true, a, st);
     if (rc) return rc;
     WgradArgs w;
     w.stash_h = a.stash_h; w.stash_dz = a.stash_dz; w.stash_e = a.stash_e; w.graw = a.graw;
     w.rows = (t1 - t0) * TILE;
     w.stride_rows = (int64_t)rows;   // a short last chunk keeps the full-chunk layer stride
-    w.n_hidden = N; w.k0 = c->k0; w.k0pad = c->k0pad;
+    w.n_hidden = N; w.k0 = c->k0; w.k0pad = k0ld;
     // (splits x (N+1)) workgroups of 8 waves, one per CU at a time: fill the chip in whole rounds
-    int splits = (2 * c->n_cu) / (N + 1);
+    int splits = b16 ? c->n_cu / N : (2 * c->n_cu) / (N + 1);
     if (splits > (int)(w.rows / 256)) splits = (int)(w.rows / 256);
     if (splits < 1) splits = 1;
     if (splits > kSplits) splits = kSplits;
     w.n_splits = splits;
     int64_t rps = (w.rows + splits - 1) / splits;
-    rps = (rps + 31) / 32 * 32;        // whole 32-sample stages
+    rps = (rps + 63) / 64 * 64;        // whole 32-/64-sample stages
     w.rows_per_split = (int)rps;
     w.partial = partial; w.partial2 = partial2;
     ReduceArgs rd;
-    rd.partial = partial; rd.partial2 = partial2; rd.n_hidden = N; rd.k0 = c->k0; rd.k0pad = c->k0pad; rd.n_splits = splits;
+    rd.partial = partial; rd.partial2 = partial2; rd.n_hidden = N; rd.k0 = c->k0; rd.k0pad = k0ld; rd.n_splits = splits;
     rd.grad = grad_flat;
-    if (F == 64) rc = launch_wgrad_t<64>(c, w, rd, N, st);
-    else if (F == 128) rc = launch_wgrad_t<128>(c, w, rd, N, st);
-    else rc = launch_wgrad_t<256>(c, w, rd, N, st);
+    if (F == 64) rc = b16 ? launch_wgrad16_t<64>(c, w, rd, N, st) : launch_wgrad_t<64>(c, w, rd, N, st);
+    else if (F == 128) rc = b16 ? launch_wgrad16_t<128>(c, w, rd, N, st) : launch_wgrad_t<128>(c, w, rd, N, st);
+    else rc = b16 ? launch_wgrad16_t<256>(c, w, rd, N, st) : launch_wgrad_t<256>(c, w, rd, N, st);
     if (rc) return rc;
   }
   return AFX_OK;
@@ -399,13 +469,13 @@ extern "C" int afx_render_backward(afx_ctx* c, int prec, const void* prepared, c
   if (c && r && r->n_rays == 0) return AFX_OK;
   int rc = check_render(c, r, "afx_render_backward");
   if (rc) return rc;
-  if (prec != AFX_PREC_F32) return fail(AFX_E_INVALID, "afx_render_backward: precision %d not built", prec);
+  if (check_prec(prec, "afx_render_backward")) return AFX_E_INVALID;
   if (!prepared || !dL_dpixel || !grad_flat) return fail(AFX_E_INVALID, "afx_render_backward: null argument");
   if (r->n_rays == 0) return AFX_OK;
   if (!r->workspace) return fail(AFX_E_WORKSPACE, "afx_render_backward: workspace required");
   hipStream_t st = (hipStream_t)stream;
   ChainArgs a = {};
-  fill_model(c, prec, prepared, a);
+  fill_model(c, prec, true, prepared, a);
   fill_render(r, a);
   a.sigma = nullptr; a.tau = nullptr;
   const size_t head = rup64((size_t)r->n_rays * 4, 256);
@@ -413,19 +483,19 @@ extern "C" int afx_render_backward(afx_ctx* c, int prec, const void* prepared, c
   float* dod = (float*)r->workspace;
   hipLaunchKernelGGL(k_finish_bwd, dim3((unsigned)((r->n_rays + 255) / 256)), dim3(256), 0, st, r->pixel, dL_dpixel, r->n_rays, dod);
   a.dod = dod;
-  return run_backward(c, a, head, (char*)r->workspace, r->workspace_bytes, grad_flat, st);
+  return run_backward(c, prec, a, head, (char*)r->workspace, r->workspace_bytes, grad_flat, st);
 }
 
 extern "C" int afx_mlp_backward(afx_ctx* c, int prec, const void* prepared, const float* pts, int64_t n_pts,
                                 const float* d_out, float* grad_flat, void* workspace, size_t workspace_bytes, void* stream) {
   if (!c || !prepared || !pts || !d_out || !grad_flat || !workspace) return fail(AFX_E_INVALID, "afx_mlp_backward: null argument");
-  if (prec != AFX_PREC_F32) return fail(AFX_E_INVALID, "afx_mlp_backward: precision %d not built", prec);
-  if (n_pts < 0 || n_pts > ((int64_t)1 << 31) - TILE) return fail(AFX_E_INVALID, "afx_mlp_backward: n_pts must be < 2^31 per call");
+  if (check_prec(prec, "afx_mlp_backward")) return AFX_E_INVALID;
+  if (n_pts < 0 || n_pts > ((int64_t)1 << 31) - 256) return fail(AFX_E_INVALID, "afx_mlp_backward: n_pts must be < 2^31 per call");
   if (n_pts == 0) return AFX_OK;
   ChainArgs a = {};
-  fill_model(c, prec, prepared, a);
+  fill_model(c, prec, true, prepared, a);
   a.n_total = n_pts; a.mode = 0; a.pts = pts; a.dod = d_out;
-  return run_backward(c, a, 0, (char*)workspace, workspace_bytes, grad_flat, (hipStream_t)stream);
+  return run_backward(c, prec, a, 0, (char*)workspace, workspace_bytes, grad_flat, (hipStream_t)stream);
 }
 
 extern "C" int afx_composite_dense(const float* raw, const float* dirs, const float* z, int z_per_ray, int64_t n_rays,

@@ -17,9 +17,10 @@ struct ChainArgs {
   uint32_t small_floats;    // multiple of 4
   uint32_t small_bytes_pad; // LDS bytes reserved for `small` (multiple of 1024)
   uint32_t slab0_bytes, slabh_bytes, slot_bytes;   // multiples of 4096
+  uint32_t slabh_stride, slabt_bytes;              // bf16: distance between forward slabs; transposed slab size
   int32_t n_hidden, k0, nq, enc, n_freq;
   // work range
-  int32_t tile0, tile1;     // global tile ids [tile0, tile1)
+  int32_t tile0, tile1;     // global tile ids [tile0, tile1), in units of the kernel's tile (128 or 256 samples)
   int64_t n_total;          // samples: n_rays * s_pad, or n_pts
   int32_t mode;             // 0 = points, 1 = rays
   // inputs

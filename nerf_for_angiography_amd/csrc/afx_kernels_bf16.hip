@@ -1,0 +1,566 @@
+// afx_kernels_bf16.hip — bf16-MFMA kernels of the hot path for gfx950 (MI355X).
+//
+// Same skeleton as afx_kernels_f32.hip (register-resident activations, weights streamed through LDS
+// as the MFMA A operand, previous accumulators fed back as the B operand) on
+// v_mfma_f32_32x32x16_bf16.  The accumulator of output tile t' converts to the B fragments of k-steps
+// 2t', 2t'+1: registers 8s..8s+7 pack pairwise into 8 bf16; element j of lane-half h is feature
+// 32t' + 16s + 8(j>>2) + 4h + (j&3), and afx_prepare_weights() stores the weight slabs in that k order.
+//
+//   X3 = false : bf16 operands, fp32 accumulate; a wave owns 64 sample columns (2 groups of 32), so every
+//                A fragment read from LDS feeds two MFMAs.
+//   X3 = true  : split-bf16: x = hi + lo (both bf16), products hi*hi + hi*lo + lo*hi, fp32 accumulate:
+//                ~2^-17 relative error per product (fp32-grade) for 3 MFMAs; 32 columns per wave.
+//   The first layer (raw world coordinates, +-100) is always split; the output layer (width -> 1) and
+//   the compositing run in fp32 on the VALU.
+#include <hip/hip_runtime.h>
+#include "afx_internal.h"
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pack2(float a, float b) {       // -> v_cvt_pk_bf16_f32 (RNE)
+  f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ float bf_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float bf_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+__device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, a), __builtin_bit_cast(s16x8, b), c, 0, 0, 0);
+}
+
+// 8 fp32 values -> one hi fragment (and the residual lo fragment)
+__device__ __forceinline__ void split_frag(const float* v, u32x4& hi, u32x4& lo) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const unsigned p = pack2(v[2 * q], v[2 * q + 1]);
+    hi[q] = p;
+    lo[q] = pack2(v[2 * q] - bf_lo(p), v[2 * q + 1] - bf_hi(p));
+  }
+}
+
+template <int F, bool X3, bool ENC, bool BWD>
+__global__ void __launch_bounds__(256, 1) k_chain_bf16(const ChainArgs a) {
+  static_assert(!(X3 && BWD), "the backward chain runs in plain bf16");
+  constexpr int NT = F / 32;
+  constexpr int NCG = X3 ? 1 : 2;          // 32-column groups per wave
+  constexpr int NK0 = ENC ? 4 : 1;         // 16-wide k-steps of the first layer
+  constexpr int MW = (NT + 1) / 2;
+  constexpr int TS = 128 * NCG;            // samples per workgroup tile
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, hh = lane >> 5;
+  const int N = a.n_hidden;
+  if (a.tile0 + (int)blockIdx.x >= a.tile1) return;
+
+  float* sm = (float*)lds;
+  for (uint32_t i = tid * 4; i < a.small_floats; i += 1024) *(f32x4*)(sm + i) = *(const f32x4*)(a.small + i);
+  char* slot0 = lds + a.small_bytes_pad;
+  uint32_t* mk = (uint32_t*)(slot0 + 2 * (size_t)a.slot_bytes);   // [((l*MW + w)*NCG + cg)*256 + tid]
+  const float* bias_perm = sm;
+  const float* wout_perm = sm + (N + 1) * F;
+  const float* aux = sm + (N + 2) * F + 4;
+  __syncthreads();
+
+  const int nfwd = NT * (N + 1);
+  const int steps_per_tile = nfwd + (BWD ? NT * N : 0);
+  int seq = 0;
+  uint32_t par = 0;
+  bool has_next = false;
+  auto step_begin = [&]() -> const u32x4* {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int ni = seq + 1;
+    bool doload = true;
+    if (ni == steps_per_tile) { ni = 0; doload = has_next; }
+    if (doload) {
+      const char* src;
+      uint32_t bytes;
+      if (ni < NT) { src = a.stream_fwd + (size_t)ni * a.slab0_bytes; bytes = a.slab0_bytes; }
+      else if (ni < nfwd) { src = a.stream_fwd + (size_t)NT * a.slab0_bytes + (size_t)(ni - NT) * a.slabh_stride; bytes = a.slabh_bytes; }
+      else { src = a.stream_bwd + (size_t)(ni - nfwd) * a.slabt_bytes; bytes = a.slabt_bytes; }
+      glds_copy(src, slot0 + (par ^ 1u) * (size_t)a.slot_bytes, bytes, wave, lane);
+    }
+    const char* cur = slot0 + par * (size_t)a.slot_bytes;
+    par ^= 1u;
+    seq = ni;
+    return (const u32x4*)cur;
+  };
+  glds_copy(a.stream_fwd, slot0, a.slab0_bytes, wave, lane);
+
+  for (int tile = a.tile0 + blockIdx.x; tile < a.tile1; tile += gridDim.x) {
+    has_next = tile + (int)gridDim.x < a.tile1;
+    int64_t n[NCG], m[NCG];
+    Sample sp[NCG];
+    u32x4 ehi[NCG][NK0], elo[NCG][NK0];
+#pragma unroll
+    for (int cg = 0; cg < NCG; ++cg) {
+      n[cg] = (int64_t)tile * TS + wave * (32 * NCG) + cg * 32 + col;
+      m[cg] = (int64_t)(tile - a.tile0) * TS + wave * (32 * NCG) + cg * 32 + col;
+      sp[cg] = make_sample(a, n[cg]);
+      // first-layer B fragments: element j of k-step q is encoded input k = 16q + 8*(lane>>5) + j
+#pragma unroll
+      for (int q = 0; q < NK0; ++q) {
+        float e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (ENC) e[j] = enc_value(16 * q + 8 * hh + j, sp[cg].px, sp[cg].py, sp[cg].pz, aux, a.enc, a.n_freq, a.k0);
+          else e[j] = (hh == 0 && j < 3) ? (j == 0 ? sp[cg].px : (j == 1 ? sp[cg].py : sp[cg].pz)) : 0.f;
+        }
+        split_frag(e, ehi[cg][q], elo[cg][q]);
+        if (BWD) {
+          float* ep = a.stash_e + m[cg] * (16 * NK0) + 16 * q + 8 * hh;
+          *(f32x4*)ep = (f32x4){e[0], e[1], e[2], e[3]};
+          *(f32x4*)(ep + 4) = (f32x4){e[4], e[5], e[6], e[7]};
+        }
+      }
+    }
+
+    u32x4 hf[NCG][NT][2];
+    u32x4 hl[X3 ? NCG : 1][X3 ? NT : 1][2];
+    float dot[NCG];
+#pragma unroll
+    for (int cg = 0; cg < NCG; ++cg) dot[cg] = 0.f;
+
+    // epilogue of one output tile: ReLU, (mask), next fragments, (stash), output-layer dot product
+    auto epilogue = [&](int l, int t, const f32x16& acc, int cg, u32x4* nf, u32x4* nl, uint32_t* mw) {
+      float v[16];
+      uint32_t bits = 0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const bool pos = acc[j] > 0.f;
+        v[j] = pos ? acc[j] : 0.f;
+        bits |= (pos ? 1u : 0u) << j;
+      }
+      if (BWD) mw[(t >> 1) * NCG + cg] |= bits << (16 * (t & 1));
+      if (l == N) {
+        const f32x4* wp = (const f32x4*)(wout_perm + (hh * NT + t) * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 w4 = wp[q];
+          dot[cg] = fmaf(v[4 * q + 0], w4[0], dot[cg]);
+          dot[cg] = fmaf(v[4 * q + 1], w4[1], dot[cg]);
+          dot[cg] = fmaf(v[4 * q + 2], w4[2], dot[cg]);
+          dot[cg] = fmaf(v[4 * q + 3], w4[3], dot[cg]);
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        if (X3) split_frag(v + 8 * s, nf[s], nl[s]);
+        else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) nf[s][q] = pack2(v[8 * s + 2 * q], v[8 * s + 2 * q + 1]);
+        }
+        if (BWD) {
+          char* row = (char*)a.stash_h + (((size_t)l * a.stash_rows + m[cg]) * F + 32 * t + 16 * s + 4 * hh) * 2;
+          *(u32x2*)row = (u32x2){nf[s][0], nf[s][1]};
+          *(u32x2*)(row + 16) = (u32x2){nf[s][2], nf[s][3]};
+        }
+      }
+    };
+    auto bias_init = [&](int l, int t) -> f32x16 {
+      const f32x4* bp = (const f32x4*)(bias_perm + ((l * 2 + hh) * NT + t) * 16);
+      const f32x4 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
+      return (f32x16){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3],
+                      b2[0], b2[1], b2[2], b2[3], b3[0], b3[1], b3[2], b3[3]};
+    };
+
+    // ---------------- layer 0 (always split: hi*hi + hi*lo + lo*hi)
+    {
+      uint32_t mw[MW * NCG];
+#pragma unroll
+      for (int w = 0; w < MW * NCG; ++w) mw[w] = 0;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const u32x4* sl = step_begin();           // [(q*2 + part)*64 + lane]
+        f32x16 acc[NCG];
+#pragma unroll
+        for (int cg = 0; cg < NCG; ++cg) acc[cg] = bias_init(0, t);
+#pragma unroll
+        for (int q = 0; q < NK0; ++q) {
+          const u32x4 ah = sl[(q * 2 + 0) * 64 + lane], al = sl[(q * 2 + 1) * 64 + lane];
+#pragma unroll
+          for (int cg = 0; cg < NCG; ++cg) {
+            acc[cg] = mfma_bf16(ah, ehi[cg][q], acc[cg]);
+            acc[cg] = mfma_bf16(ah, elo[cg][q], acc[cg]);
+            acc[cg] = mfma_bf16(al, ehi[cg][q], acc[cg]);
+          }
+        }
+#pragma unroll
+        for (int cg = 0; cg < NCG; ++cg) epilogue(0, t, acc[cg], cg, hf[cg][t], hl[X3 ? cg : 0][X3 ? t : 0], mw);
+      }
+      if (BWD) {
+#pragma unroll
+        for (int w = 0; w < MW * NCG; ++w) mk[(0 * MW * NCG + w) * 256 + tid] = mw[w];
+      }
+    }
+    // ---------------- hidden layers
+    for (int l = 1; l <= N; ++l) {
+      u32x4 nf[NCG][NT][2];
+      u32x4 nl[X3 ? NCG : 1][X3 ? NT : 1][2];
+      uint32_t mw[MW * NCG];
+#pragma unroll
+      for (int w = 0; w < MW * NCG; ++w) mw[w] = 0;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const u32x4* sl = step_begin();           // hi block [u*64 + lane], then lo block (X3)
+        f32x16 acc[NCG];
+#pragma unroll
+        for (int cg = 0; cg < NCG; ++cg) acc[cg] = bias_init(l, t);
+#pragma unroll
+        for (int u = 0; u < 2 * NT; ++u) {
+          const u32x4 ah = sl[u * 64 + lane];
+          if (X3) {
+            const u32x4 al = sl[(2 * NT + u) * 64 + lane];
+            acc[0] = mfma_bf16(ah, hf[0][u >> 1][u & 1], acc[0]);
+            acc[0] = mfma_bf16(ah, hl[0][X3 ? (u >> 1) : 0][u & 1], acc[0]);
+            acc[0] = mfma_bf16(al, hf[0][u >> 1][u & 1], acc[0]);
+          } else {
+#pragma unroll
+            for (int cg = 0; cg < NCG; ++cg) acc[cg] = mfma_bf16(ah, hf[cg][u >> 1][u & 1], acc[cg]);
+          }
+        }
+#pragma unroll
+        for (int cg = 0; cg < NCG; ++cg) epilogue(l, t, acc[cg], cg, nf[cg][t], nl[X3 ? cg : 0][X3 ? t : 0], mw);
+      }
+      if (BWD) {
+#pragma unroll
+        for (int w = 0; w < MW * NCG; ++w) mk[(l * MW * NCG + w) * 256 + tid] = mw[w];
+      }
+#pragma unroll
+      for (int cg = 0; cg < NCG; ++cg)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          hf[cg][t][0] = nf[cg][t][0]; hf[cg][t][1] = nf[cg][t][1];
+          if (X3) { hl[cg][t][0] = nl[cg][t][0]; hl[cg][t][1] = nl[cg][t][1]; }
+        }
+    }
+
+    // ---------------- output layer + Beer-Lambert / outputs
+    float g[NCG];
+#pragma unroll
+    for (int cg = 0; cg < NCG; ++cg) {
+      float d = dot[cg];
+      d += __shfl_xor(d, 32);
+      const float raw = d + sm[(N + 2) * F];
+      g[cg] = 0.f;
+      if (a.mode == 0) {
+        if (!BWD) { if (hh == 0 && sp[cg].live) a.out[n[cg]] = a.apply_sigmoid ? sigmoidf_(raw) : raw; }
+        else g[cg] = sp[cg].live ? a.dod[n[cg]] : 0.f;
+      } else {
+        const float sig = sigmoidf_(raw);
+        const float tau = sp[cg].live ? __fmul_rn(sig, sp[cg].dt) : 0.f;
+        if (hh == 0 && sp[cg].live) {
+          if (a.sigma) a.sigma[(int64_t)sp[cg].ray * a.n_samples + sp[cg].s] = sig;
+          if (a.tau) a.tau[(int64_t)sp[cg].ray * a.n_samples + sp[cg].s] = tau;
+        }
+        if (!BWD) {
+          float od = tau;
+#pragma unroll
+          for (int sh = 16; sh >= 1; sh >>= 1) od += __shfl_xor(od, sh);
+          if (lane == 0 && n[cg] < a.n_total) {
+            const int gpr = a.s_pad / GROUP;
+            a.od_part[(int64_t)sp[cg].ray * gpr + (int)((n[cg] - (int64_t)sp[cg].ray * a.s_pad) / GROUP)] = od;
+          }
+        } else if (sp[cg].live) g[cg] = a.dod[sp[cg].ray] * sp[cg].dt * (sig * (1.f - sig));
+      }
+    }
+
+    if (BWD) {
+      // ---------------- input-gradient chain, bf16 operands, fp32 accumulate
+      u32x4 dz[NCG][NT][2];
+#pragma unroll
+      for (int cg = 0; cg < NCG; ++cg) {
+        if (hh == 0) a.graw[m[cg]] = g[cg];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const uint32_t bits = mk[((N * MW + (t >> 1)) * NCG + cg) * 256 + tid] >> (16 * (t & 1));
+          const f32x4* wp = (const f32x4*)(wout_perm + (hh * NT + t) * 16);
+          float v[16];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 w4 = wp[q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[4 * q + e] = ((bits >> (4 * q + e)) & 1u) ? w4[e] * g[cg] : 0.f;
+          }
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dz[cg][t][s][q] = pack2(v[8 * s + 2 * q], v[8 * s + 2 * q + 1]);
+        }
+      }
+      auto stash_dz = [&](int l) {
+#pragma unroll
+        for (int cg = 0; cg < NCG; ++cg)
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+              char* row = (char*)a.stash_dz + (((size_t)l * a.stash_rows + m[cg]) * F + 32 * t + 16 * s + 4 * hh) * 2;
+              *(u32x2*)row = (u32x2){dz[cg][t][s][0], dz[cg][t][s][1]};
+              *(u32x2*)(row + 16) = (u32x2){dz[cg][t][s][2], dz[cg][t][s][3]};
+            }
+      };
+      for (int l = N; l >= 1; --l) {
+        stash_dz(l);
+        u32x4 dn[NCG][NT][2];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const u32x4* sl = step_begin();
+          f32x16 acc[NCG];
+#pragma unroll
+          for (int cg = 0; cg < NCG; ++cg) acc[cg] = (f32x16){0.f};
+#pragma unroll
+          for (int u = 0; u < 2 * NT; ++u) {
+            const u32x4 ah = sl[u * 64 + lane];
+#pragma unroll
+            for (int cg = 0; cg < NCG; ++cg) acc[cg] = mfma_bf16(ah, dz[cg][u >> 1][u & 1], acc[cg]);
+          }
+#pragma unroll
+          for (int cg = 0; cg < NCG; ++cg) {
+            const uint32_t bits = mk[(((l - 1) * MW + (t >> 1)) * NCG + cg) * 256 + tid] >> (16 * (t & 1));
+            float v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = ((bits >> j) & 1u) ? acc[cg][j] : 0.f;
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) dn[cg][t][s][q] = pack2(v[8 * s + 2 * q], v[8 * s + 2 * q + 1]);
+          }
+        }
+#pragma unroll
+        for (int cg = 0; cg < NCG; ++cg)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) { dz[cg][t][0] = dn[cg][t][0]; dz[cg][t][1] = dn[cg][t][1]; }
+      }
+      stash_dz(0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ---------------------------------------------------------------------------------------
+// Weight gradients of the hidden layers from the bf16 stashes:
+//   dW_l[o][i] = sum_n dZ_l[n][o] * H_{l-1}[n][i],  db_l[o] = sum_n dZ_l[n][o]
+// grid = (n_splits, N) (blockIdx.y = l-1), block = 512 (8 waves).  64-sample stages of both stashes
+// ([sample][feature] rows) are copied to LDS by LDS-DMA with an XOR chunk swizzle applied on the
+// SOURCE address (LDS destination must stay lane-linear); both MFMA operands need the sample index
+// as k, i.e. a column of the image: ds_read_b64_tr_b16 (hardware transpose read) delivers it.
+// ---------------------------------------------------------------------------------------
+template <int F> __device__ __forceinline__ int swz(int row) { return F == 64 ? ((row >> 1) & 1) << 2 : (row & 3) << 2; }
+
+template <int F>
+__global__ void __launch_bounds__(512) k_wgrad_bf16(const WgradArgs a) {
+  constexpr int NT = F / 32;
+  constexpr int TR = NT >= 2 ? NT / 2 : 1, WR = NT / TR;   // row tiles per wave, waves along rows
+  constexpr int TC = NT >= 4 ? NT / 4 : 1, WC = NT / TC;
+  constexpr int KB = 64;
+  constexpr int RB = 2 * F;                  // bytes per stash row
+  constexpr int CHUNK = KB * RB;             // bytes of one operand stage
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, hh = lane >> 5;
+  const int layer = blockIdx.y + 1, split = blockIdx.x;
+  const char* A = (const char*)a.stash_dz + (size_t)layer * a.stride_rows * RB;
+  const char* B = (const char*)a.stash_h + (size_t)(layer - 1) * a.stride_rows * RB;
+  int64_t r0 = (int64_t)split * a.rows_per_split;
+  int64_t r1 = r0 + a.rows_per_split;
+  if (r1 > a.rows) r1 = a.rows;
+  const int nst = r1 > r0 ? (int)((r1 - r0) / KB) : 0;
+  const bool active = wave < WR * WC;
+  const int wr = wave / WC, wc = wave % WC;
+
+  f32x16 acc[TR][TC];
+#pragma unroll
+  for (int i = 0; i < TR; ++i)
+#pragma unroll
+    for (int j = 0; j < TC; ++j) acc[i][j] = (f32x16){0.f};
+  float bsum = 0.f;
+
+  auto stage_load = [&](int st, int buf) {
+    char* dA = lds + buf * 2 * CHUNK;
+    char* dB = dA + CHUNK;
+    const char* gA = A + (r0 + (int64_t)st * KB) * RB;
+    const char* gB = B + (r0 + (int64_t)st * KB) * RB;
+    for (int off = wave * 1024; off < CHUNK; off += 8192) {
+      const int L = off + lane * 16;
+      const int row = L / RB, ch = (L % RB) >> 4;
+      const int src = row * RB + ((ch ^ swz<F>(row)) << 4);
+      __builtin_amdgcn_global_load_lds(GPTR(gA + src), LPTR(dA + off), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GPTR(gB + src), LPTR(dB + off), 16, 0, 0);
+    }
+  };
+  // transpose-read address of lane for (k-step ks, read rd, 32-feature tile base fb0) inside an image
+  const int g4 = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+  auto tr_off = [&](int ks, int rd, int fb0) -> int {
+    const int row = ks * 16 + 8 * (g4 >> 1) + 4 * rd + tq;
+    const int c = fb0 + 16 * (g4 & 1) + 4 * tp;
+    return row * RB + (((c >> 3) ^ swz<F>(row)) << 4) + 8 * (tp & 1);
+  };
+  auto tr_frag = [&](const char* img, int ks, int fb0) -> u32x4 {
+    const s16x4 x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + tr_off(ks, 0, fb0)));
+    const s16x4 y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + tr_off(ks, 1, fb0)));
+    const s16x8 f = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+    return __builtin_bit_cast(u32x4, f);
+  };
+
+  if (nst > 0) stage_load(0, 0);
+  for (int st = 0; st < nst; ++st) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (st + 1 < nst) stage_load(st + 1, (st + 1) & 1);
+    const char* sA = lds + (st & 1) * 2 * CHUNK;
+    const char* sB = sA + CHUNK;
+    if (active) {
+#pragma unroll
+      for (int ks = 0; ks < KB / 16; ++ks) {
+        u32x4 af[TR], bf[TC];
+#pragma unroll
+        for (int i = 0; i < TR; ++i) af[i] = tr_frag(sA, ks, 32 * (wr * TR + i));
+#pragma unroll
+        for (int j = 0; j < TC; ++j) bf[j] = tr_frag(sB, ks, 32 * (wc * TC + j));
+#pragma unroll
+        for (int i = 0; i < TR; ++i)
+#pragma unroll
+          for (int j = 0; j < TC; ++j) acc[i][j] = mfma_bf16(af[i], bf[j], acc[i][j]);
+      }
+    }
+    // bias gradient: column sums of the dZ image on the VALU (512 threads: F features x 512/F row groups)
+    {
+      const int f = tid % F, part = tid / F;
+      constexpr int PARTS = 512 / F;
+#pragma unroll 8
+      for (int r = part; r < KB; r += PARTS) {
+        const unsigned short v = *(const unsigned short*)(sA + r * RB + ((((f >> 3) ^ swz<F>(r)) << 4)) + (f & 7) * 2);
+        bsum += __builtin_bit_cast(float, (unsigned)v << 16);
+      }
+    }
+  }
+  float* P = a.partial + ((size_t)layer * a.n_splits + split) * F * F;
+  if (active) {
+#pragma unroll
+    for (int i = 0; i < TR; ++i)
+#pragma unroll
+      for (int j = 0; j < TC; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          P[(size_t)(32 * (wr * TR + i) + rowperm(r) + 4 * hh) * F + 32 * (wc * TC + j) + col] = acc[i][j][r];
+  }
+  __syncthreads();
+  float* red = (float*)lds;
+  red[tid] = bsum;
+  __syncthreads();
+  if (tid < F) {
+    float s = 0.f;
+    for (int q = 0; q < 512 / F; ++q) s += red[q * F + tid];
+    a.partial2[((size_t)layer * a.n_splits + split) * (F + 4) + tid] = s;
+  }
+}
+
+// First-layer weight gradient (dW_0 = dZ_0^T E, K0 columns, fp32 on the VALU), its bias, and the output
+// layer (dw_out = sum_n g_n H_N[n], db_out = sum_n g_n) from the bf16 stashes.
+// grid = (n_splits, 2): y = 0 first layer, y = 1 output layer; block = F threads (one per feature).
+template <int F, bool ENC>
+__global__ void k_small_grads_bf16(const WgradArgs a) {
+  constexpr int KMAX = ENC ? 64 : 4;
+  const int f = threadIdx.x, split = blockIdx.x;
+  int64_t r0 = (int64_t)split * a.rows_per_split;
+  int64_t r1 = r0 + a.rows_per_split;
+  if (r1 > a.rows) r1 = a.rows;
+  const unsigned short* dz0 = (const unsigned short*)a.stash_dz;
+  if (blockIdx.y == 0) {
+    float acc[KMAX];
+#pragma unroll
+    for (int c = 0; c < KMAX; ++c) acc[c] = 0.f;
+    float bs = 0.f;
+    for (int64_t r = r0; r < r1; ++r) {
+      const float d = __builtin_bit_cast(float, (unsigned)dz0[r * F + f] << 16);
+      bs += d;
+      const float* e = a.stash_e + r * a.k0pad;
+#pragma unroll
+      for (int c = 0; c < KMAX; ++c)
+        if (c < a.k0) acc[c] = fmaf(d, e[c], acc[c]);
+    }
+    float* P = a.partial + ((size_t)0 * a.n_splits + split) * F * F;
+#pragma unroll
+    for (int c = 0; c < KMAX; ++c)
+      if (c < a.k0) P[(size_t)f * a.k0pad + c] = acc[c];
+    a.partial2[((size_t)0 * a.n_splits + split) * (F + 4) + f] = bs;
+  } else {
+    const unsigned short* hN = (const unsigned short*)a.stash_h + (size_t)a.n_hidden * a.stride_rows * F;
+    float s = 0.f, sg = 0.f;
+    for (int64_t r = r0; r < r1; ++r) {
+      const float g = a.graw[r];
+      s = fmaf(g, __builtin_bit_cast(float, (unsigned)hN[r * F + f] << 16), s);
+      sg += g;
+    }
+    float* P2 = a.partial2 + ((size_t)(a.n_hidden + 1) * a.n_splits + split) * (F + 4);
+    P2[f] = s;
+    if (f == 0) P2[F] = sg;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Weight re-tiling for the bf16 kernels.  parts = 2 stores [hi | lo] slabs (X3 forward).
+// ---------------------------------------------------------------------------------------
+struct PrepArgs16 {
+  const float* params;
+  char* prepared;
+  int32_t F, n_hidden, k0, nk0, parts;
+  uint32_t slab0_off, slab0_bytes, fwd_off, slabh_stride, bwd_off, slabt_bytes;
+};
+
+__device__ __forceinline__ unsigned short bf16_rne(float x) { return (unsigned short)(pack2(x, 0.f) & 0xffffu); }
+
+__global__ void k_prepare_bf16(const PrepArgs16 p) {
+  const int F = p.F, NT = F / 32, N = p.n_hidden;
+  const size_t hidden0 = (size_t)F * p.k0 + F;
+  const size_t stride = (size_t)F * F + F;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+  // layer-0 slabs: slab t, element [((q*2 + part)*64 + lane)*8 + j] = W0[32t + (lane&31)][16q + 8(lane>>5) + j]
+  {
+    unsigned short* s0 = (unsigned short*)(p.prepared + p.slab0_off);
+    const int64_t per = p.slab0_bytes / 2;
+    for (int64_t i = gid; i < per * NT; i += gsz) {
+      const int t = (int)(i / per);
+      const int e = (int)(i % per);
+      const int j = e & 7, lane = (e >> 3) & 63, qp = e >> 9;
+      const int part = qp & 1, q = qp >> 1;
+      const int k = 16 * q + 8 * (lane >> 5) + j;
+      float w = 0.f;
+      if (q < p.nk0 && k < p.k0) w = p.params[(size_t)(32 * t + (lane & 31)) * p.k0 + k];
+      const unsigned short hi = bf16_rne(w);
+      s0[i] = part == 0 ? hi : bf16_rne(w - __builtin_bit_cast(float, (unsigned)hi << 16));
+    }
+  }
+  // hidden slabs: element [((part*2NT + u)*64 + lane)*8 + j], u = 2t' + s,
+  //   k = 32t' + 16s + 8(j>>2) + 4(lane>>5) + (j&3), r = 32t + (lane&31)
+  //   fwd: W_l[r][k] (parts hi[,lo]);  bwd: W_l[k][r] (hi only)
+  const int64_t per_part = (int64_t)2 * NT * 64 * 8;
+  const int64_t nslab = (int64_t)N * NT;
+  const int64_t nfwd = nslab * p.parts * per_part;
+  for (int64_t i = gid; i < nfwd + nslab * per_part; i += gsz) {
+    const bool isb = i >= nfwd;
+    const int64_t ii = isb ? i - nfwd : i;
+    const int64_t per_slab = isb ? per_part : p.parts * per_part;
+    const int64_t slab = ii / per_slab;
+    const int64_t e0 = ii % per_slab;
+    const int part = (int)(e0 / per_part);
+    const int e = (int)(e0 % per_part);
+    const int j = e & 7, lane = (e >> 3) & 63, u = e >> 9;
+    const int tp = u >> 1, s = u & 1;
+    const int t = (int)(slab % NT), lidx = (int)(slab / NT);
+    const int l = isb ? N - lidx : 1 + lidx;
+    const float* W = p.params + hidden0 + (size_t)(l - 1) * stride;
+    const int r = 32 * t + (lane & 31);
+    const int k = 32 * tp + 16 * s + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
+    const float w = isb ? W[(size_t)k * F + r] : W[(size_t)r * F + k];
+    const unsigned short hi = bf16_rne(w);
+    const unsigned short val = part == 0 ? hi : bf16_rne(w - __builtin_bit_cast(float, (unsigned)hi << 16));
+    unsigned short* dst = isb ? (unsigned short*)(p.prepared + p.bwd_off + slab * p.slabt_bytes)
+                              : (unsigned short*)(p.prepared + p.fwd_off + slab * p.slabh_stride);
+    dst[e0] = val;
+  }
+}

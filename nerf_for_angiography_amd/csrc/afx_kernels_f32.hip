@@ -534,7 +534,7 @@ struct PrepArgs {
   const float* params;
   const float* enc_aux;
   char* prepared;
-  int32_t F, n_hidden, k0, nq, enc, n_freq;
+  int32_t F, n_hidden, k0, nq, enc, n_freq, weights;   // weights = 0: only the `small` section (bf16 modes)
   uint32_t small_off, slab0_off, fwd_off, bwd_off, slab0_bytes, slabh_bytes, small_floats;
 };
 
@@ -568,6 +568,7 @@ __global__ void k_prepare_f32(const PrepArgs p) {
     }
     sm[i] = v;
   }
+  if (!p.weights) return;
   // slab0: [q][t][lane] = W0[32t + (lane&31)][2q + (lane>>5)]
   float* s0 = (float*)(p.prepared + p.slab0_off);
   for (int64_t i = gid; i < p.slab0_bytes / 4; i += gsz) {
