@@ -2,6 +2,7 @@
 // Validates arguments, carves the caller-owned workspace, launches the gfx950 kernels.
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string>
 #include <vector>
@@ -37,6 +38,7 @@ struct afx_ctx {
   int n_cu;
   std::set<const void*> attr_done;
   bool profiling;
+  int nw_plain;          // waves per workgroup of the plain-bf16 chain kernels (8, or 4 via AFX_NW=4)
   std::vector<ProfRec> recs;
 };
 
@@ -121,6 +123,8 @@ extern "C" int afx_create(const afx_model_desc* d, afx_ctx** out) {
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
     c->n_cu = prop.multiProcessorCount;
   c->profiling = false;
+  c->nw_plain = 8;
+  if (const char* e = getenv("AFX_NW")) { if (atoi(e) == 4) c->nw_plain = 4; }
   *out = c;
   return AFX_OK;
 }
@@ -177,12 +181,14 @@ struct BwdLayout {
   size_t fixed_bytes, per_tile_bytes;
 };
 static const int kSplits = 64;
+static const int kSmallBlocks = 512;   // blocks (and partial records) of k_small_grads_bf16
 static BwdLayout bwd_layout(const afx_ctx* c, int prec, int64_t n_rays) {
   const size_t F = c->d.width, N = c->d.n_hidden;
   BwdLayout B;
   size_t fixed = rup64((size_t)n_rays * 4, 256);   // dod (rays mode only)
   fixed += rup64((N + 1) * (size_t)kSplits * F * F * 4, 256);     // partial
   fixed += rup64((N + 2) * (size_t)kSplits * (F + 4) * 4, 256);   // partial2
+  if (prec != AFX_PREC_F32) fixed += rup64((size_t)kSmallBlocks * (F * 16 * nk0_of(c) + 2 * F + 4) * 4, 256);   // partial_s
   B.fixed_bytes = fixed;
   if (prec == AFX_PREC_F32) B.per_tile_bytes = (size_t)128 * 4 * (2 * (N + 1) * F + c->k0pad + 1);
   else B.per_tile_bytes = (size_t)256 * (2 * (N + 1) * F * 2 + 4 * 16 * nk0_of(c) + 4);
@@ -245,14 +251,14 @@ extern "C" int afx_prepare_weights(afx_ctx* c, int prec, const float* params, co
 }
 
 template <class K>
-static int launch_chain_k(afx_ctx* c, K kern, int which, const ChainArgs& a, size_t lds_bytes, int grid, hipStream_t st) {
+static int launch_chain_k(afx_ctx* c, K kern, int which, const ChainArgs& a, size_t lds_bytes, int grid, hipStream_t st, int threads = 256) {
   if (!c->attr_done.count((const void*)kern)) {
     HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     c->attr_done.insert((const void*)kern);
   }
   {
     ProfScope ps(c, which, st);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds_bytes, st, a);
   }
   HIPCHK(hipGetLastError());
   return AFX_OK;
@@ -264,14 +270,21 @@ static int launch_chain_f(afx_ctx* c, int prec, bool bwd, const ChainArgs& a, si
   const bool enc = c->d.enc != AFX_ENC_NONE;
   if (prec == AFX_PREC_F32)
     return bwd ? launch_chain_k(c, k_chain_f32<F, true>, which, a, lds, grid, st) : launch_chain_k(c, k_chain_f32<F, false>, which, a, lds, grid, st);
+  if (prec == AFX_PREC_BF16X3 && !bwd)
+    return enc ? launch_chain_k(c, k_chain_bf16<F, true, true, false, 4>, which, a, lds, grid, st)
+               : launch_chain_k(c, k_chain_bf16<F, true, false, false, 4>, which, a, lds, grid, st);
+  if (c->nw_plain == 4) {
+    if (bwd)
+      return enc ? launch_chain_k(c, k_chain_bf16<F, false, true, true, 4>, which, a, lds, grid, st)
+                 : launch_chain_k(c, k_chain_bf16<F, false, false, true, 4>, which, a, lds, grid, st);
+    return enc ? launch_chain_k(c, k_chain_bf16<F, false, true, false, 4>, which, a, lds, grid, st)
+               : launch_chain_k(c, k_chain_bf16<F, false, false, false, 4>, which, a, lds, grid, st);
+  }
   if (bwd)
-    return enc ? launch_chain_k(c, k_chain_bf16<F, false, true, true>, which, a, lds, grid, st)
-               : launch_chain_k(c, k_chain_bf16<F, false, false, true>, which, a, lds, grid, st);
-  if (prec == AFX_PREC_BF16X3)
-    return enc ? launch_chain_k(c, k_chain_bf16<F, true, true, false>, which, a, lds, grid, st)
-               : launch_chain_k(c, k_chain_bf16<F, true, false, false>, which, a, lds, grid, st);
-  return enc ? launch_chain_k(c, k_chain_bf16<F, false, true, false>, which, a, lds, grid, st)
-             : launch_chain_k(c, k_chain_bf16<F, false, false, false>, which, a, lds, grid, st);
+    return enc ? launch_chain_k(c, k_chain_bf16<F, false, true, true, 8>, which, a, lds, grid, st, 512)
+               : launch_chain_k(c, k_chain_bf16<F, false, false, true, 8>, which, a, lds, grid, st, 512);
+  return enc ? launch_chain_k(c, k_chain_bf16<F, false, true, false, 8>, which, a, lds, grid, st, 512)
+             : launch_chain_k(c, k_chain_bf16<F, false, false, false, 8>, which, a, lds, grid, st, 512);
 }
 
 static int launch_chain(afx_ctx* c, int prec, bool bwd, const ChainArgs& a, hipStream_t st) {
@@ -401,10 +414,11 @@ static int launch_wgrad16_t(afx_ctx* c, const WgradArgs& w, const ReduceArgs& rd
     ProfScope ps(c, AFX_K_WGRAD, st);
     hipLaunchKernelGGL(k_wgrad_bf16<F>, dim3(w.n_splits, N), dim3(512), lds, st, w);
   }
-  if (c->d.enc != AFX_ENC_NONE) hipLaunchKernelGGL((k_small_grads_bf16<F, true>), dim3(w.n_splits, 2), dim3(F), 0, st, w);
-  else hipLaunchKernelGGL((k_small_grads_bf16<F, false>), dim3(w.n_splits, 2), dim3(F), 0, st, w);
+  if (c->d.enc != AFX_ENC_NONE) hipLaunchKernelGGL((k_small_grads_bf16<F, true>), dim3(rd.n_small), dim3(F), 0, st, w);
+  else hipLaunchKernelGGL((k_small_grads_bf16<F, false>), dim3(rd.n_small), dim3(F), 0, st, w);
   hipLaunchKernelGGL(k_reduce_w<F>, dim3((F * F + 255) / 256, N + 1), dim3(256), 0, st, rd);
   hipLaunchKernelGGL(k_reduce_b<F>, dim3(1, N + 2), dim3(F), 0, st, rd);
+  hipLaunchKernelGGL(k_reduce_small<F>, dim3((unsigned)((F * rd.k0pad + 2 * F + 1 + 255) / 256)), dim3(256), 0, st, rd);
   HIPCHK(hipGetLastError());
   return AFX_OK;
 }
@@ -427,6 +441,8 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
   size_t off = head;
   float* partial = (float*)(ws + off); off += rup64((size_t)(N + 1) * kSplits * F * F * 4, 256);
   float* partial2 = (float*)(ws + off); off += rup64((size_t)(N + 2) * kSplits * (F + 4) * 4, 256);
+  float* partial_s = (float*)(ws + off);
+  if (b16) off += rup64((size_t)kSmallBlocks * (F * k0ld + 2 * F + 4) * 4, 256);
   const size_t rows = (size_t)chunk * TILE;
   a.stash_h = (float*)(ws + off); off += (size_t)(N + 1) * rows * F * esz;
   a.stash_dz = (float*)(ws + off); off += (size_t)(N + 1) * rows * F * esz;
@@ -452,10 +468,11 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
     int64_t rps = (w.rows + splits - 1) / splits;
     rps = (rps + 63) / 64 * 64;        // whole 32-/64-sample stages
     w.rows_per_split = (int)rps;
-    w.partial = partial; w.partial2 = partial2;
+    w.partial = partial; w.partial2 = partial2; w.partial_s = partial_s;
     ReduceArgs rd;
     rd.partial = partial; rd.partial2 = partial2; rd.n_hidden = N; rd.k0 = c->k0; rd.k0pad = k0ld; rd.n_splits = splits;
-    rd.grad = grad_flat;
+    rd.grad = grad_flat; rd.hidden_only = b16 ? 1 : 0; rd.partial_s = partial_s;
+    rd.n_small = (int)(w.rows / 64 < kSmallBlocks ? w.rows / 64 : kSmallBlocks);
     if (F == 64) rc = b16 ? launch_wgrad16_t<64>(c, w, rd, N, st) : launch_wgrad_t<64>(c, w, rd, N, st);
     else if (F == 128) rc = b16 ? launch_wgrad16_t<128>(c, w, rd, N, st) : launch_wgrad_t<128>(c, w, rd, N, st);
     else rc = b16 ? launch_wgrad16_t<256>(c, w, rd, N, st) : launch_wgrad_t<256>(c, w, rd, N, st);

@@ -61,12 +61,16 @@ struct WgradArgs {
   int32_t n_splits, rows_per_split;   // rows_per_split even
   float* partial;           // [(N+1), n_splits, F*F]
   float* partial2;          // [(N+2), n_splits, F+4]
+  float* partial_s;         // bf16 path: [n_small, F*k0pad + 2F + 4] first-layer / output-layer partials
 };
 
 struct ReduceArgs {
   const float* partial;
   const float* partial2;
   int32_t n_hidden, k0, k0pad, n_splits;
+  int32_t hidden_only;      // bf16 path: layer 0 and the output layer are reduced by k_reduce_small
+  int32_t n_small;
+  const float* partial_s;
   float* grad;              // flat parameter gradient, accumulated into
 };
 

@@ -42,23 +42,29 @@ __device__ __forceinline__ void split_frag(const float* v, u32x4& hi, u32x4& lo)
   }
 }
 
-template <int F, bool X3, bool ENC, bool BWD>
-__global__ void __launch_bounds__(256, 1) k_chain_bf16(const ChainArgs a) {
+// NW = wavefronts per workgroup.  NW = 4: one wave per SIMD with up to 512 registers (needed by the split
+// mode, whose hi+lo activations fill them; plain bf16 then takes 2 column groups per wave).  NW = 8: two
+// waves per SIMD with <= 256 registers and one column group each: the partner wave's MFMAs cover a wave's
+// epilogue VALU work, barrier and LDS latencies.
+template <int F, bool X3, bool ENC, bool BWD, int NW>
+__global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs a) {
   static_assert(!(X3 && BWD), "the backward chain runs in plain bf16");
+  static_assert(!(X3 && NW != 4), "the split mode needs 512 registers per wave");
   constexpr int NT = F / 32;
-  constexpr int NCG = X3 ? 1 : 2;          // 32-column groups per wave
+  constexpr int NCG = (X3 || NW == 8) ? 1 : 2;   // 32-column groups per wave
+  constexpr int NTH = 64 * NW;
   constexpr int NK0 = ENC ? 4 : 1;         // 16-wide k-steps of the first layer
   constexpr int MW = (NT + 1) / 2;
-  constexpr int TS = 128 * NCG;            // samples per workgroup tile
+  constexpr int TS = NW * 32 * NCG;        // samples per workgroup tile
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, hh = lane >> 5;
   const int N = a.n_hidden;
   if (a.tile0 + (int)blockIdx.x >= a.tile1) return;
 
   float* sm = (float*)lds;
-  for (uint32_t i = tid * 4; i < a.small_floats; i += 1024) *(f32x4*)(sm + i) = *(const f32x4*)(a.small + i);
+  for (uint32_t i = tid * 4; i < a.small_floats; i += NTH * 4) *(f32x4*)(sm + i) = *(const f32x4*)(a.small + i);
   char* slot0 = lds + a.small_bytes_pad;
-  uint32_t* mk = (uint32_t*)(slot0 + 2 * (size_t)a.slot_bytes);   // [((l*MW + w)*NCG + cg)*256 + tid]
+  uint32_t* mk = (uint32_t*)(slot0 + 2 * (size_t)a.slot_bytes);   // [((l*MW + w)*NCG + cg)*NTH + tid]
   const float* bias_perm = sm;
   const float* wout_perm = sm + (N + 1) * F;
   const float* aux = sm + (N + 2) * F + 4;
@@ -69,9 +75,19 @@ __global__ void __launch_bounds__(256, 1) k_chain_bf16(const ChainArgs a) {
   int seq = 0;
   uint32_t par = 0;
   bool has_next = false;
+  // Step protocol: wait for THIS step's slab (LDS-DMA issued one step ago), barrier (which also retires
+  // every reader of the other slot), start the DMA of the next slab, compute.  In the backward kernel
+  // each step issues exactly SPS stash stores AFTER its DMA; vmcnt counts in issue order, so vmcnt(SPS)
+  // retires the DMA while the step's own stores stay in flight (a vmcnt(0) here costs a full store
+  // round-trip per step).  Raw s_barrier: __syncthreads() would re-insert vmcnt(0).
+  constexpr int SPS = 2 * NCG;
+  bool first_step = true;
   auto step_begin = [&]() -> const u32x4* {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (BWD && !first_step) {
+      if (SPS == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+    } else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    first_step = false;
     int ni = seq + 1;
     bool doload = true;
     if (ni == steps_per_tile) { ni = 0; doload = has_next; }
@@ -81,14 +97,14 @@ __global__ void __launch_bounds__(256, 1) k_chain_bf16(const ChainArgs a) {
       if (ni < NT) { src = a.stream_fwd + (size_t)ni * a.slab0_bytes; bytes = a.slab0_bytes; }
       else if (ni < nfwd) { src = a.stream_fwd + (size_t)NT * a.slab0_bytes + (size_t)(ni - NT) * a.slabh_stride; bytes = a.slabh_bytes; }
       else { src = a.stream_bwd + (size_t)(ni - nfwd) * a.slabt_bytes; bytes = a.slabt_bytes; }
-      glds_copy(src, slot0 + (par ^ 1u) * (size_t)a.slot_bytes, bytes, wave, lane);
+      glds_copy(src, slot0 + (par ^ 1u) * (size_t)a.slot_bytes, bytes, wave, lane, NW);
     }
     const char* cur = slot0 + par * (size_t)a.slot_bytes;
     par ^= 1u;
     seq = ni;
     return (const u32x4*)cur;
   };
-  glds_copy(a.stream_fwd, slot0, a.slab0_bytes, wave, lane);
+  glds_copy(a.stream_fwd, slot0, a.slab0_bytes, wave, lane, NW);
 
   for (int tile = a.tile0 + blockIdx.x; tile < a.tile1; tile += gridDim.x) {
     has_next = tile + (int)gridDim.x < a.tile1;
@@ -154,9 +170,9 @@ __global__ void __launch_bounds__(256, 1) k_chain_bf16(const ChainArgs a) {
           for (int q = 0; q < 4; ++q) nf[s][q] = pack2(v[8 * s + 2 * q], v[8 * s + 2 * q + 1]);
         }
         if (BWD) {
-          char* row = (char*)a.stash_h + (((size_t)l * a.stash_rows + m[cg]) * F + 32 * t + 16 * s + 4 * hh) * 2;
-          *(u32x2*)row = (u32x2){nf[s][0], nf[s][1]};
-          *(u32x2*)(row + 16) = (u32x2){nf[s][2], nf[s][3]};
+          // stash position of feature 32t+16s+8(j>>2)+4h+(j&3) is 32t+16s+8h+j (bits 2,3 swapped): one
+          // 16-byte store per fragment; the weight-gradient kernels undo the permutation (fperm)
+          *(u32x4*)((char*)a.stash_h + (((size_t)l * a.stash_rows + m[cg]) * F + 32 * t + 16 * s + 8 * hh) * 2) = nf[s];
         }
       }
     };
@@ -193,7 +209,7 @@ __global__ void __launch_bounds__(256, 1) k_chain_bf16(const ChainArgs a) {
       }
       if (BWD) {
 #pragma unroll
-        for (int w = 0; w < MW * NCG; ++w) mk[(0 * MW * NCG + w) * 256 + tid] = mw[w];
+        for (int w = 0; w < MW * NCG; ++w) mk[(0 * MW * NCG + w) * NTH + tid] = mw[w];
       }
     }
     // ---------------- hidden layers
@@ -227,7 +243,7 @@ __global__ void __launch_bounds__(256, 1) k_chain_bf16(const ChainArgs a) {
       }
       if (BWD) {
 #pragma unroll
-        for (int w = 0; w < MW * NCG; ++w) mk[(l * MW * NCG + w) * 256 + tid] = mw[w];
+        for (int w = 0; w < MW * NCG; ++w) mk[(l * MW * NCG + w) * NTH + tid] = mw[w];
       }
 #pragma unroll
       for (int cg = 0; cg < NCG; ++cg)
@@ -276,7 +292,7 @@ __global__ void __launch_bounds__(256, 1) k_chain_bf16(const ChainArgs a) {
         if (hh == 0) a.graw[m[cg]] = g[cg];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          const uint32_t bits = mk[((N * MW + (t >> 1)) * NCG + cg) * 256 + tid] >> (16 * (t & 1));
+          const uint32_t bits = mk[((N * MW + (t >> 1)) * NCG + cg) * NTH + tid] >> (16 * (t & 1));
           const f32x4* wp = (const f32x4*)(wout_perm + (hh * NT + t) * 16);
           float v[16];
 #pragma unroll
@@ -291,24 +307,19 @@ __global__ void __launch_bounds__(256, 1) k_chain_bf16(const ChainArgs a) {
             for (int q = 0; q < 4; ++q) dz[cg][t][s][q] = pack2(v[8 * s + 2 * q], v[8 * s + 2 * q + 1]);
         }
       }
-      auto stash_dz = [&](int l) {
+      auto stash_dz_tile = [&](int l, int t) {
 #pragma unroll
         for (int cg = 0; cg < NCG; ++cg)
 #pragma unroll
-          for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-              char* row = (char*)a.stash_dz + (((size_t)l * a.stash_rows + m[cg]) * F + 32 * t + 16 * s + 4 * hh) * 2;
-              *(u32x2*)row = (u32x2){dz[cg][t][s][0], dz[cg][t][s][1]};
-              *(u32x2*)(row + 16) = (u32x2){dz[cg][t][s][2], dz[cg][t][s][3]};
-            }
+          for (int s = 0; s < 2; ++s)
+            *(u32x4*)((char*)a.stash_dz + (((size_t)l * a.stash_rows + m[cg]) * F + 32 * t + 16 * s + 8 * hh) * 2) = dz[cg][t][s];
       };
       for (int l = N; l >= 1; --l) {
-        stash_dz(l);
         u32x4 dn[NCG][NT][2];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const u32x4* sl = step_begin();
+          stash_dz_tile(l, t);                   // SPS stores per step, after the step's DMA
           f32x16 acc[NCG];
 #pragma unroll
           for (int cg = 0; cg < NCG; ++cg) acc[cg] = (f32x16){0.f};
@@ -320,7 +331,7 @@ __global__ void __launch_bounds__(256, 1) k_chain_bf16(const ChainArgs a) {
           }
 #pragma unroll
           for (int cg = 0; cg < NCG; ++cg) {
-            const uint32_t bits = mk[(((l - 1) * MW + (t >> 1)) * NCG + cg) * 256 + tid] >> (16 * (t & 1));
+            const uint32_t bits = mk[(((l - 1) * MW + (t >> 1)) * NCG + cg) * NTH + tid] >> (16 * (t & 1));
             float v[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) v[j] = ((bits >> j) & 1u) ? acc[cg][j] : 0.f;
@@ -335,7 +346,8 @@ __global__ void __launch_bounds__(256, 1) k_chain_bf16(const ChainArgs a) {
 #pragma unroll
           for (int t = 0; t < NT; ++t) { dz[cg][t][0] = dn[cg][t][0]; dz[cg][t][1] = dn[cg][t][1]; }
       }
-      stash_dz(0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) stash_dz_tile(0, t);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -349,6 +361,9 @@ __global__ void __launch_bounds__(256, 1) k_chain_bf16(const ChainArgs a) {
 // SOURCE address (LDS destination must stay lane-linear); both MFMA operands need the sample index
 // as k, i.e. a column of the image: ds_read_b64_tr_b16 (hardware transpose read) delivers it.
 // ---------------------------------------------------------------------------------------
+// stash position <-> feature index: swap bits 2 and 3 (self-inverse); see the stash stores of k_chain_bf16
+__device__ __forceinline__ int fperm(int p) { return (p & ~12) | ((p & 4) << 1) | ((p & 8) >> 1); }
+
 template <int F> __device__ __forceinline__ int swz(int row) { return F == 64 ? ((row >> 1) & 1) << 2 : (row & 3) << 2; }
 
 template <int F>
@@ -445,7 +460,7 @@ __global__ void __launch_bounds__(512) k_wgrad_bf16(const WgradArgs a) {
       for (int j = 0; j < TC; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          P[(size_t)(32 * (wr * TR + i) + rowperm(r) + 4 * hh) * F + 32 * (wc * TC + j) + col] = acc[i][j][r];
+          P[(size_t)fperm(32 * (wr * TR + i) + rowperm(r) + 4 * hh) * F + fperm(32 * (wc * TC + j) + col)] = acc[i][j][r];
   }
   __syncthreads();
   float* red = (float*)lds;
@@ -454,51 +469,66 @@ __global__ void __launch_bounds__(512) k_wgrad_bf16(const WgradArgs a) {
   if (tid < F) {
     float s = 0.f;
     for (int q = 0; q < 512 / F; ++q) s += red[q * F + tid];
-    a.partial2[((size_t)layer * a.n_splits + split) * (F + 4) + tid] = s;
+    a.partial2[((size_t)layer * a.n_splits + split) * (F + 4) + fperm(tid)] = s;
   }
 }
 
 // First-layer weight gradient (dW_0 = dZ_0^T E, K0 columns, fp32 on the VALU), its bias, and the output
-// layer (dw_out = sum_n g_n H_N[n], db_out = sum_n g_n) from the bf16 stashes.
-// grid = (n_splits, 2): y = 0 first layer, y = 1 output layer; block = F threads (one per feature).
+// layer (dw_out = sum_n g_n H_N[n], db_out = sum_n g_n) from the bf16 stashes: one pass over dZ_0, H_N, E, g.
+// grid = n_small blocks, block = F threads (thread p = stash position; feature = fperm(p)).
+// Block b writes its partial record of SS = F*k0pad + 2F + 4 floats; k_reduce_small sums the records in order.
+
 template <int F, bool ENC>
 __global__ void k_small_grads_bf16(const WgradArgs a) {
   constexpr int KMAX = ENC ? 64 : 4;
-  const int f = threadIdx.x, split = blockIdx.x;
-  int64_t r0 = (int64_t)split * a.rows_per_split;
-  int64_t r1 = r0 + a.rows_per_split;
+  const int p = threadIdx.x, f = fperm(p);
+  const int64_t per = (a.rows + gridDim.x - 1) / gridDim.x;
+  int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per;
   if (r1 > a.rows) r1 = a.rows;
   const unsigned short* dz0 = (const unsigned short*)a.stash_dz;
-  if (blockIdx.y == 0) {
-    float acc[KMAX];
+  const unsigned short* hN = (const unsigned short*)a.stash_h + (size_t)a.n_hidden * a.stride_rows * F;
+  float acc[KMAX];
 #pragma unroll
-    for (int c = 0; c < KMAX; ++c) acc[c] = 0.f;
-    float bs = 0.f;
-    for (int64_t r = r0; r < r1; ++r) {
-      const float d = __builtin_bit_cast(float, (unsigned)dz0[r * F + f] << 16);
-      bs += d;
-      const float* e = a.stash_e + r * a.k0pad;
-#pragma unroll
-      for (int c = 0; c < KMAX; ++c)
-        if (c < a.k0) acc[c] = fmaf(d, e[c], acc[c]);
-    }
-    float* P = a.partial + ((size_t)0 * a.n_splits + split) * F * F;
+  for (int c = 0; c < KMAX; ++c) acc[c] = 0.f;
+  float bs = 0.f, s = 0.f, sg = 0.f;
+#pragma unroll 4
+  for (int64_t r = r0; r < r1; ++r) {
+    const float d = __builtin_bit_cast(float, (unsigned)dz0[r * F + p] << 16);
+    const float g = a.graw[r];
+    s = fmaf(g, __builtin_bit_cast(float, (unsigned)hN[r * F + p] << 16), s);
+    sg += g;
+    bs += d;
+    const float* e = a.stash_e + r * a.k0pad;
 #pragma unroll
     for (int c = 0; c < KMAX; ++c)
-      if (c < a.k0) P[(size_t)f * a.k0pad + c] = acc[c];
-    a.partial2[((size_t)0 * a.n_splits + split) * (F + 4) + f] = bs;
-  } else {
-    const unsigned short* hN = (const unsigned short*)a.stash_h + (size_t)a.n_hidden * a.stride_rows * F;
-    float s = 0.f, sg = 0.f;
-    for (int64_t r = r0; r < r1; ++r) {
-      const float g = a.graw[r];
-      s = fmaf(g, __builtin_bit_cast(float, (unsigned)hN[r * F + f] << 16), s);
-      sg += g;
-    }
-    float* P2 = a.partial2 + ((size_t)(a.n_hidden + 1) * a.n_splits + split) * (F + 4);
-    P2[f] = s;
-    if (f == 0) P2[F] = sg;
+      if (c < a.k0) acc[c] = fmaf(d, e[c], acc[c]);
   }
+  const size_t SS = (size_t)F * a.k0pad + 2 * F + 4;
+  float* P = a.partial_s + (size_t)blockIdx.x * SS;
+#pragma unroll
+  for (int c = 0; c < KMAX; ++c)
+    if (c < a.k0) P[(size_t)f * a.k0pad + c] = acc[c];
+  P[(size_t)F * a.k0pad + f] = bs;
+  P[(size_t)F * a.k0pad + F + f] = s;
+  if (p == 0) P[(size_t)F * a.k0pad + 2 * F] = sg;
+}
+
+template <int F>
+__global__ void k_reduce_small(const ReduceArgs a) {
+  const size_t SS = (size_t)F * a.k0pad + 2 * F + 4;
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e > (size_t)F * a.k0pad + 2 * F) return;
+  const size_t wout = (size_t)F * a.k0 + F + (size_t)a.n_hidden * ((size_t)F * F + F);
+  size_t dst;
+  if (e < (size_t)F * a.k0pad) {
+    const int row = (int)(e / a.k0pad), c = (int)(e % a.k0pad);
+    if (c >= a.k0) return;
+    dst = (size_t)row * a.k0 + c;
+  } else if (e < (size_t)F * a.k0pad + F) dst = (size_t)F * a.k0 + (e - (size_t)F * a.k0pad);
+  else dst = wout + (e - (size_t)F * a.k0pad - F);       // F output weights, then the output bias
+  float s = 0.f;
+  for (int b = 0; b < a.n_small; ++b) s += a.partial_s[(size_t)b * SS + e];
+  a.grad[dst] += s;
 }
 
 // ---------------------------------------------------------------------------------------

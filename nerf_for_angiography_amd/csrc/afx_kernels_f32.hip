@@ -25,8 +25,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // LDS-DMA copy of `bytes` (multiple of 4096) by the 4 waves of the workgroup: each wave
 // instruction moves 64 lanes x 16 B = 1 KiB, destination = wave-uniform base + lane*16.
-__device__ __forceinline__ void glds_copy(const char* g, char* l, uint32_t bytes, int wave, int lane) {
-  for (uint32_t off = (uint32_t)wave * 1024u; off < bytes; off += 4096u)
+__device__ __forceinline__ void glds_copy(const char* g, char* l, uint32_t bytes, int wave, int lane, uint32_t nwaves = 4) {
+  for (uint32_t off = (uint32_t)wave * 1024u; off < bytes; off += nwaves * 1024u)
     __builtin_amdgcn_global_load_lds(GPTR(g + off + lane * 16), LPTR(l + off), 16, 0, 0);
 }
 
@@ -494,6 +494,7 @@ __global__ void __launch_bounds__(1024) k_colsum_f32(const WgradArgs a) {
 template <int F>
 __global__ void k_reduce_w(const ReduceArgs a) {
   const int layer = blockIdx.y;
+  if (a.hidden_only && layer == 0) return;
   const int ncols = layer == 0 ? a.k0pad : F;
   const int ncr = layer == 0 ? a.k0 : F;
   const int e = blockIdx.x * 256 + threadIdx.x;
@@ -511,6 +512,7 @@ __global__ void k_reduce_w(const ReduceArgs a) {
 template <int F>
 __global__ void k_reduce_b(const ReduceArgs a) {
   const int y = blockIdx.y, f = threadIdx.x;
+  if (a.hidden_only && (y == 0 || y == a.n_hidden + 1)) return;
   float s = 0.f, sg = 0.f;
   for (int sp = 0; sp < a.n_splits; ++sp) {
     const float* P = a.partial2 + ((size_t)y * a.n_splits + sp) * (F + 4);
