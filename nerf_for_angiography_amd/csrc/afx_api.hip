@@ -181,7 +181,7 @@ struct BwdLayout {
   size_t fixed_bytes, per_tile_bytes;
 };
 static const int kSplits = 64;
-static const int kSmallBlocks = 512;   // blocks (and partial records) of k_small_grads_bf16
+static const int kSmallBlocks = 256;   // blocks (and partial records) of k_small_grads_bf16
 static BwdLayout bwd_layout(const afx_ctx* c, int prec, int64_t n_rays) {
   const size_t F = c->d.width, N = c->d.n_hidden;
   BwdLayout B;
@@ -406,7 +406,7 @@ static int launch_wgrad_t(afx_ctx* c, const WgradArgs& w, const ReduceArgs& rd, 
 template <int F>
 static int launch_wgrad16_t(afx_ctx* c, const WgradArgs& w, const ReduceArgs& rd, int N, hipStream_t st) {
   {
-    const size_t lds = (size_t)4 * 64 * 2 * F;          // 2 stages x (dZ + H image of 64 samples)
+    const size_t lds = (size_t)4 * (F / 8) * (64 * 16 + 64);   // 2 stages x (dZ + H image of 64 samples, padded chunk columns)
     if (!c->attr_done.count((const void*)k_wgrad_bf16<F>)) {
       HIPCHK(hipFuncSetAttribute((const void*)k_wgrad_bf16<F>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       c->attr_done.insert((const void*)k_wgrad_bf16<F>);
@@ -414,8 +414,8 @@ static int launch_wgrad16_t(afx_ctx* c, const WgradArgs& w, const ReduceArgs& rd
     ProfScope ps(c, AFX_K_WGRAD, st);
     hipLaunchKernelGGL(k_wgrad_bf16<F>, dim3(w.n_splits, N), dim3(512), lds, st, w);
   }
-  if (c->d.enc != AFX_ENC_NONE) hipLaunchKernelGGL((k_small_grads_bf16<F, true>), dim3(rd.n_small), dim3(F), 0, st, w);
-  else hipLaunchKernelGGL((k_small_grads_bf16<F, false>), dim3(rd.n_small), dim3(F), 0, st, w);
+  if (c->d.enc != AFX_ENC_NONE) hipLaunchKernelGGL((k_small_grads_bf16<F, true>), dim3(rd.n_small, F / 64 * 4), dim3(256), 0, st, w);
+  else hipLaunchKernelGGL((k_small_grads_bf16<F, false>), dim3(rd.n_small, F / 64), dim3(256), 0, st, w);
   hipLaunchKernelGGL(k_reduce_w<F>, dim3((F * F + 255) / 256, N + 1), dim3(256), 0, st, rd);
   hipLaunchKernelGGL(k_reduce_b<F>, dim3(1, N + 2), dim3(F), 0, st, rd);
   hipLaunchKernelGGL(k_reduce_small<F>, dim3((unsigned)((F * rd.k0pad + 2 * F + 1 + 255) / 256)), dim3(256), 0, st, rd);
@@ -472,7 +472,7 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
     ReduceArgs rd;
     rd.partial = partial; rd.partial2 = partial2; rd.n_hidden = N; rd.k0 = c->k0; rd.k0pad = k0ld; rd.n_splits = splits;
     rd.grad = grad_flat; rd.hidden_only = b16 ? 1 : 0; rd.partial_s = partial_s;
-    rd.n_small = (int)(w.rows / 64 < kSmallBlocks ? w.rows / 64 : kSmallBlocks);
+    rd.n_small = kSmallBlocks;      // records; every record is written (possibly with zero rows)
     if (F == 64) rc = b16 ? launch_wgrad16_t<64>(c, w, rd, N, st) : launch_wgrad_t<64>(c, w, rd, N, st);
     else if (F == 128) rc = b16 ? launch_wgrad16_t<128>(c, w, rd, N, st) : launch_wgrad_t<128>(c, w, rd, N, st);
     else rc = b16 ? launch_wgrad16_t<256>(c, w, rd, N, st) : launch_wgrad_t<256>(c, w, rd, N, st);

@@ -46,6 +46,11 @@ __device__ __forceinline__ void split_frag(const float* v, u32x4& hi, u32x4& lo)
 // mode, whose hi+lo activations fill them; plain bf16 then takes 2 column groups per wave).  NW = 8: two
 // waves per SIMD with <= 256 registers and one column group each: the partner wave's MFMAs cover a wave's
 // epilogue VALU work, barrier and LDS latencies.
+// byte offset of the 16-byte chunk `ch` (8 stash positions) of stash row `r` inside one layer's stash
+template <int F> __device__ __forceinline__ size_t stash_off(int64_t r, int ch) {
+  return ((((size_t)(r >> 5) * (F / 8) + ch) << 5) + (size_t)(r & 31)) << 4;
+}
+
 template <int F, bool X3, bool ENC, bool BWD, int NW>
 __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs a) {
   static_assert(!(X3 && BWD), "the backward chain runs in plain bf16");
@@ -170,9 +175,10 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
           for (int q = 0; q < 4; ++q) nf[s][q] = pack2(v[8 * s + 2 * q], v[8 * s + 2 * q + 1]);
         }
         if (BWD) {
-          // stash position of feature 32t+16s+8(j>>2)+4h+(j&3) is 32t+16s+8h+j (bits 2,3 swapped): one
-          // 16-byte store per fragment; the weight-gradient kernels undo the permutation (fperm)
-          *(u32x4*)((char*)a.stash_h + (((size_t)l * a.stash_rows + m[cg]) * F + 32 * t + 16 * s + 8 * hh) * 2) = nf[s];
+          // stash position of feature 32t+16s+8(j>>2)+4h+(j&3) is p = 32t+16s+8h+j (bits 2,3 swapped; the
+          // weight-gradient kernels undo it with fperm).  Layout [row>>5][p>>3][row&31][8 bf16]: the 64 lanes
+          // of this store write one contiguous 1 KiB run (32 samples x 16 B for h = 0, then for h = 1).
+          *(u32x4*)((char*)a.stash_h + (size_t)l * a.stash_rows * (F * 2) + stash_off<F>(m[cg], 4 * t + 2 * s + hh)) = nf[s];
         }
       }
     };
@@ -312,7 +318,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
         for (int cg = 0; cg < NCG; ++cg)
 #pragma unroll
           for (int s = 0; s < 2; ++s)
-            *(u32x4*)((char*)a.stash_dz + (((size_t)l * a.stash_rows + m[cg]) * F + 32 * t + 16 * s + 8 * hh) * 2) = dz[cg][t][s];
+            *(u32x4*)((char*)a.stash_dz + (size_t)l * a.stash_rows * (F * 2) + stash_off<F>(m[cg], 4 * t + 2 * s + hh)) = dz[cg][t][s];
       };
       for (int l = N; l >= 1; --l) {
         u32x4 dn[NCG][NT][2];
@@ -364,16 +370,17 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
 // stash position <-> feature index: swap bits 2 and 3 (self-inverse); see the stash stores of k_chain_bf16
 __device__ __forceinline__ int fperm(int p) { return (p & ~12) | ((p & 4) << 1) | ((p & 8) >> 1); }
 
-template <int F> __device__ __forceinline__ int swz(int row) { return F == 64 ? ((row >> 1) & 1) << 2 : (row & 3) << 2; }
-
 template <int F>
 __global__ void __launch_bounds__(512) k_wgrad_bf16(const WgradArgs a) {
   constexpr int NT = F / 32;
   constexpr int TR = NT >= 2 ? NT / 2 : 1, WR = NT / TR;   // row tiles per wave, waves along rows
   constexpr int TC = NT >= 4 ? NT / 4 : 1, WC = NT / TC;
-  constexpr int KB = 64;
-  constexpr int RB = 2 * F;                  // bytes per stash row
-  constexpr int CHUNK = KB * RB;             // bytes of one operand stage
+  constexpr int KB = 64;                     // samples per stage (two 32-row stash groups)
+  constexpr int NCH = F / 8;                 // 16-byte chunks per stash row
+  constexpr int CS = KB * 16 + 64;           // LDS bytes per chunk column: 64 rows x 16 B, +64 B so that the
+                                             // four chunks a transpose-read touches fall on disjoint banks
+  constexpr int IMG = NCH * CS;              // one operand image
+  constexpr int RB = 2 * F;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, hh = lane >> 5;
   const int layer = blockIdx.y + 1, split = blockIdx.x;
@@ -393,25 +400,24 @@ __global__ void __launch_bounds__(512) k_wgrad_bf16(const WgradArgs a) {
     for (int j = 0; j < TC; ++j) acc[i][j] = (f32x16){0.f};
   float bsum = 0.f;
 
+  // one LDS-DMA instruction per chunk column: lane = stage row; source = two contiguous 512-byte runs
   auto stage_load = [&](int st, int buf) {
-    char* dA = lds + buf * 2 * CHUNK;
-    char* dB = dA + CHUNK;
-    const char* gA = A + (r0 + (int64_t)st * KB) * RB;
-    const char* gB = B + (r0 + (int64_t)st * KB) * RB;
-    for (int off = wave * 1024; off < CHUNK; off += 8192) {
-      const int L = off + lane * 16;
-      const int row = L / RB, ch = (L % RB) >> 4;
-      const int src = row * RB + ((ch ^ swz<F>(row)) << 4);
-      __builtin_amdgcn_global_load_lds(GPTR(gA + src), LPTR(dA + off), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(GPTR(gB + src), LPTR(dB + off), 16, 0, 0);
+    char* dA = lds + buf * 2 * IMG;
+    char* dB = dA + IMG;
+    const int64_t g0 = (r0 + (int64_t)st * KB) >> 5;
+    for (int c = wave; c < NCH; c += 8) {
+      const size_t src = ((((size_t)(g0 + hh) * NCH + c) << 5) + col) << 4;
+      __builtin_amdgcn_global_load_lds(GPTR(A + src), LPTR(dA + c * CS), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GPTR(B + src), LPTR(dB + c * CS), 16, 0, 0);
     }
   };
-  // transpose-read address of lane for (k-step ks, read rd, 32-feature tile base fb0) inside an image
+  // transpose-read (ds_read_b64_tr_b16): lane 4q+p of each 16-lane group supplies the address of stage row
+  // (block row q), positions 4p..4p+3; lane i of the group receives position i of the 4 rows.
   const int g4 = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
   auto tr_off = [&](int ks, int rd, int fb0) -> int {
     const int row = ks * 16 + 8 * (g4 >> 1) + 4 * rd + tq;
     const int c = fb0 + 16 * (g4 & 1) + 4 * tp;
-    return row * RB + (((c >> 3) ^ swz<F>(row)) << 4) + 8 * (tp & 1);
+    return (c >> 3) * CS + row * 16 + 8 * (tp & 1);
   };
   auto tr_frag = [&](const char* img, int ks, int fb0) -> u32x4 {
     const s16x4 x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + tr_off(ks, 0, fb0)));
@@ -425,8 +431,8 @@ __global__ void __launch_bounds__(512) k_wgrad_bf16(const WgradArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (st + 1 < nst) stage_load(st + 1, (st + 1) & 1);
-    const char* sA = lds + (st & 1) * 2 * CHUNK;
-    const char* sB = sA + CHUNK;
+    const char* sA = lds + (st & 1) * 2 * IMG;
+    const char* sB = sA + IMG;
     if (active) {
 #pragma unroll
       for (int ks = 0; ks < KB / 16; ++ks) {
@@ -441,13 +447,13 @@ __global__ void __launch_bounds__(512) k_wgrad_bf16(const WgradArgs a) {
           for (int j = 0; j < TC; ++j) acc[i][j] = mfma_bf16(af[i], bf[j], acc[i][j]);
       }
     }
-    // bias gradient: column sums of the dZ image on the VALU (512 threads: F features x 512/F row groups)
+    // bias gradient: column sums of the dZ image on the VALU (512 threads: F positions x 512/F row groups)
     {
       const int f = tid % F, part = tid / F;
       constexpr int PARTS = 512 / F;
 #pragma unroll 8
       for (int r = part; r < KB; r += PARTS) {
-        const unsigned short v = *(const unsigned short*)(sA + r * RB + ((((f >> 3) ^ swz<F>(r)) << 4)) + (f & 7) * 2);
+        const unsigned short v = *(const unsigned short*)(sA + (f >> 3) * CS + r * 16 + (f & 7) * 2);
         bsum += __builtin_bit_cast(float, (unsigned)v << 16);
       }
     }
@@ -478,39 +484,76 @@ __global__ void __launch_bounds__(512) k_wgrad_bf16(const WgradArgs a) {
 // grid = n_small blocks, block = F threads (thread p = stash position; feature = fperm(p)).
 // Block b writes its partial record of SS = F*k0pad + 2F + 4 floats; k_reduce_small sums the records in order.
 
+// grid = (n_records, F/64 * (ENC ? 4 : 1)), block = 256 = 8 chunk columns x 32 rows: a wave reads two contiguous
+// 512-byte runs of the chunk-major stash.  blockIdx.y selects 64 stash positions (and, with an encoding, which
+// 2 of each chunk's 8 positions this block accumulates, to bound the accumulator count).
 template <int F, bool ENC>
-__global__ void k_small_grads_bf16(const WgradArgs a) {
+__global__ void __launch_bounds__(256) k_small_grads_bf16(const WgradArgs a) {
   constexpr int KMAX = ENC ? 64 : 4;
-  const int p = threadIdx.x, f = fperm(p);
-  const int64_t per = (a.rows + gridDim.x - 1) / gridDim.x;
-  int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per;
-  if (r1 > a.rows) r1 = a.rows;
-  const unsigned short* dz0 = (const unsigned short*)a.stash_dz;
-  const unsigned short* hN = (const unsigned short*)a.stash_h + (size_t)a.n_hidden * a.stride_rows * F;
-  float acc[KMAX];
+  constexpr int PPT = ENC ? 2 : 8;
+  constexpr int NCH = F / 8;
+  const int cq = threadIdx.x >> 5, rr = threadIdx.x & 31;
+  const int ygrp = ENC ? blockIdx.y >> 2 : blockIdx.y, sub = ENC ? (blockIdx.y & 3) : 0;
+  const int ch = ygrp * 8 + cq;                               // chunk column of this thread
+  const int64_t ngroups = a.rows >> 5;
+  const int64_t per = (ngroups + gridDim.x - 1) / gridDim.x;
+  int64_t g0 = (int64_t)blockIdx.x * per, g1 = g0 + per;
+  if (g1 > ngroups) g1 = ngroups;
+  const char* dz0 = (const char*)a.stash_dz;
+  const char* hN = (const char*)a.stash_h + (size_t)a.n_hidden * a.stride_rows * F * 2;
+  float acc[PPT][KMAX], bs[PPT], so[PPT];
 #pragma unroll
-  for (int c = 0; c < KMAX; ++c) acc[c] = 0.f;
-  float bs = 0.f, s = 0.f, sg = 0.f;
-#pragma unroll 4
-  for (int64_t r = r0; r < r1; ++r) {
-    const float d = __builtin_bit_cast(float, (unsigned)dz0[r * F + p] << 16);
-    const float g = a.graw[r];
-    s = fmaf(g, __builtin_bit_cast(float, (unsigned)hN[r * F + p] << 16), s);
-    sg += g;
-    bs += d;
-    const float* e = a.stash_e + r * a.k0pad;
+  for (int i = 0; i < PPT; ++i) {
+    bs[i] = so[i] = 0.f;
 #pragma unroll
-    for (int c = 0; c < KMAX; ++c)
-      if (c < a.k0) acc[c] = fmaf(d, e[c], acc[c]);
+    for (int c = 0; c < KMAX; ++c) acc[i][c] = 0.f;
   }
+  float sg = 0.f;
+#pragma unroll 2
+  for (int64_t g = g0; g < g1; ++g) {
+    const size_t off = ((((size_t)g * NCH + ch) << 5) + rr) << 4;
+    const u32x4 x = *(const u32x4*)(dz0 + off), y = *(const u32x4*)(hN + off);
+    const int64_t r = (g << 5) + rr;
+    const float gr = a.graw[r];
+    sg += gr;
+    const float* e = a.stash_e + r * a.k0pad;
+    float ev[KMAX];
+#pragma unroll
+    for (int c = 0; c < KMAX; ++c) ev[c] = c < a.k0 ? e[c] : 0.f;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const int e8 = ENC ? 2 * sub + i : i;                   // element of the 16-byte chunk
+      const unsigned dw = e8 < 2 ? x[0] : (e8 < 4 ? x[1] : (e8 < 6 ? x[2] : x[3]));
+      const unsigned hw = e8 < 2 ? y[0] : (e8 < 4 ? y[1] : (e8 < 6 ? y[2] : y[3]));
+      const float d = (e8 & 1) ? bf_hi(dw) : bf_lo(dw);
+      const float h = (e8 & 1) ? bf_hi(hw) : bf_lo(hw);
+      bs[i] += d;
+      so[i] = fmaf(gr, h, so[i]);
+#pragma unroll
+      for (int c = 0; c < KMAX; ++c) acc[i][c] = fmaf(d, ev[c], acc[i][c]);
+    }
+  }
+  // sum over the 32 rows (lanes of one half-wave)
+  auto red32 = [&](float v) -> float {
+#pragma unroll
+    for (int sh = 16; sh >= 1; sh >>= 1) v += __shfl_xor(v, sh);
+    return v;
+  };
   const size_t SS = (size_t)F * a.k0pad + 2 * F + 4;
   float* P = a.partial_s + (size_t)blockIdx.x * SS;
 #pragma unroll
-  for (int c = 0; c < KMAX; ++c)
-    if (c < a.k0) P[(size_t)f * a.k0pad + c] = acc[c];
-  P[(size_t)F * a.k0pad + f] = bs;
-  P[(size_t)F * a.k0pad + F + f] = s;
-  if (p == 0) P[(size_t)F * a.k0pad + 2 * F] = sg;
+  for (int i = 0; i < PPT; ++i) {
+    const int f = fperm(ch * 8 + (ENC ? 2 * sub + i : i));
+#pragma unroll
+    for (int c = 0; c < KMAX; ++c) {
+      const float v = red32(acc[i][c]);
+      if (rr == 0 && c < a.k0) P[(size_t)f * a.k0pad + c] = v;
+    }
+    const float vb = red32(bs[i]), vo = red32(so[i]);
+    if (rr == 0) { P[(size_t)F * a.k0pad + f] = vb; P[(size_t)F * a.k0pad + F + f] = vo; }
+  }
+  const float vg = red32(sg);
+  if (blockIdx.y == 0 && threadIdx.x == 0) P[(size_t)F * a.k0pad + 2 * F] = vg;
 }
 
 template <int F>
