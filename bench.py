@@ -51,11 +51,13 @@ def main():
     ap.add_argument("--cpu-rays", type=int, default=2048)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--workspace-gib", type=float, default=24.0)
+    ap.add_argument("--unfused", action="store_true",
+                    help="render -> mse_loss -> autograd backward (forward rendered separately) instead of the fused train step")
     args = ap.parse_args()
 
     from nerf_for_angiography_amd import dist as afx_dist
     from nerf_for_angiography_amd.model.CPPN import CPPN
-    from nerf_for_angiography_amd.render import render_projection, render_rays
+    from nerf_for_angiography_amd.render import render_projection, render_rays, train_step_mse, projection_spec
     from nerf_for_angiography_amd.phantomdata.proj_helpers import source_matrix
     from nerf_for_angiography_amd.phantomdata.helpers import capsule_tree, capsule_mu, ray_tracing, get_ray_values
 
@@ -96,11 +98,17 @@ def main():
                                        z_gt, batch_rays=16384).reshape(-1).contiguous())
     del o, d
 
+    fused = not args.unfused and args.precision != "f32"
+
     def step(i):
         opt.zero_grad(set_to_none=True)
-        out = render_projection(model, poses[i], W, H, focal, S, near, far)
-        loss = torch.nn.functional.mse_loss(out.rgb_map, targets[i])
-        loss.backward()
+        if fused:       # forward + MSE + backward in one pass per ray chunk (afx_train_step_mse)
+            loss, _ = train_step_mse(model, projection_spec(poses[i], W, H, focal, S, near, far), targets[i],
+                                     n_global=W * H)
+        else:
+            out = render_projection(model, poses[i], W, H, focal, S, near, far)
+            loss = torch.nn.functional.mse_loss(out.rgb_map, targets[i])
+            loss.backward()
         opt.step()
         return loss
 
@@ -145,7 +153,8 @@ def main():
               "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
               "vs_baseline": None, "dtype": DTYPE_NAME[args.precision], "data": "synthetic",
               "config": {"workload": f"{W}x{H} projection, {S} samples/ray, {args.layers}x{args.width} CPPN MLP, "
-                                     "uniform mid-point march (acc convention), fwd+bwd+Adam, one projection per GPU per step",
+                                     "uniform mid-point march (acc convention), fwd+bwd+Adam, one projection per GPU per step"
+                                     + (", fused train step" if fused else ", render + autograd"),
                          "rays_per_step_per_gpu": W * H, "parallelism": f"ray-batch dp{world}"},
               "final_loss": round(float(loss), 6), "roofline": roofline}
 

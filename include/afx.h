@@ -146,6 +146,15 @@ int afx_render_forward(afx_ctx* ctx, int prec, const void* prepared, const afx_r
 int afx_render_backward(afx_ctx* ctx, int prec, const void* prepared, const afx_render_args* args,
                         const float* dL_dpixel, float* grad_flat, void* stream);
 
+/* One fused training pass over a ray batch — the body of nerf/run_nerf_acc.py:287-306 (render, mse_loss,
+ * backward) without materialising anything between the steps: the backward kernel's forward recompute IS the
+ * forward pass; it composites each ray in-kernel, forms dL/dpixel = 2 (pixel - target) * inv_n
+ * (L = inv_n * sum_r (pixel_r - target_r)^2, inv_n = 1 / global ray count) and runs the gradient chain.
+ * grad_flat += dL/dparams; args->pixel receives the rendered pixels.  bf16 precisions only; the padded
+ * samples per ray must divide 256 (S <= 256) so that a ray never straddles a workgroup tile. */
+int afx_train_step_mse(afx_ctx* ctx, int prec, const void* prepared, const afx_render_args* args,
+                       const float* target, float inv_n, float* grad_flat, void* stream);
+
 /* render_volume_density(radiance_field, ray_directions, depth_values) for one output channel —
  * nerf/nerf_helpers.py:59-123 (C == 1 branch), from a raw tensor already in memory.
  * raw[R,S], dirs[R,3], z[S] (z_per_ray=0) or [R,S]; all outputs optional except rgb_map.

@@ -45,6 +45,8 @@ _SIGS = {
     "afx_render_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(RenderArgs), C.c_void_p]),
     "afx_render_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(RenderArgs), C.c_void_p, C.c_void_p,
                                       C.c_void_p]),
+    "afx_train_step_mse": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(RenderArgs), C.c_void_p, C.c_float, C.c_void_p,
+                                     C.c_void_p]),
     "afx_composite_dense": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int32, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "afx_composite_dense_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int32,

@@ -291,7 +291,7 @@ static int launch_chain(afx_ctx* c, int prec, bool bwd, const ChainArgs& a, hipS
   const int F = c->d.width, N = c->d.n_hidden;
   size_t lds = (size_t)a.small_bytes_pad + 2 * (size_t)a.slot_bytes;
   const int ncg = (is_bf16(prec) && (bwd || prec == AFX_PREC_BF16)) ? 2 : 1;
-  if (bwd) lds += (size_t)(N + 1) * ((c->nt + 1) / 2) * ncg * 256 * 4;
+  if (bwd) lds += (size_t)(N + 1) * ((c->nt + 1) / 2) * ncg * 256 * 4 + 256;   // ReLU masks + per-group optical depths
   if (lds > 160 * 1024) return fail(AFX_E_INVALID, "model needs %zu B of LDS (> 160 KiB)", lds);
   const int tiles = a.tile1 - a.tile0;
   if (tiles <= 0) return AFX_OK;
@@ -319,7 +319,7 @@ extern "C" int afx_mlp_infer(afx_ctx* c, int prec, const void* prepared, const f
                              int apply_sigmoid, void* stream) {
   if (!c || !prepared || !pts || !out) return fail(AFX_E_INVALID, "afx_mlp_infer: null argument");
   if (check_prec(prec, "afx_mlp_infer")) return AFX_E_INVALID;
-  if (n_pts < 0 || n_pts > (int64_t)1 << 37) return fail(AFX_E_INVALID, "afx_mlp_infer: bad n_pts");
+  if (n_pts < 0 || n_pts > ((int64_t)1 << 31) - 256) return fail(AFX_E_INVALID, "afx_mlp_infer: n_pts must be < 2^31 per call");
   if (n_pts == 0) return AFX_OK;
   ChainArgs a = {};
   fill_model(c, prec, false, prepared, a);
@@ -449,6 +449,7 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
   a.stash_e = (float*)(ws + off); off += rows * k0ld * 4;
   a.graw = (float*)(ws + off);
   a.stash_rows = (int64_t)rows;
+  if (const char* e = getenv("AFX_DEBUG")) a.debug = atoi(e);
   for (int64_t t0 = 0; t0 < tiles; t0 += chunk) {
     const int64_t t1 = t0 + chunk < tiles ? t0 + chunk : tiles;
     a.tile0 = (int)t0; a.tile1 = (int)t1;
@@ -501,6 +502,22 @@ extern "C" int afx_render_backward(afx_ctx* c, int prec, const void* prepared, c
   hipLaunchKernelGGL(k_finish_bwd, dim3((unsigned)((r->n_rays + 255) / 256)), dim3(256), 0, st, r->pixel, dL_dpixel, r->n_rays, dod);
   a.dod = dod;
   return run_backward(c, prec, a, head, (char*)r->workspace, r->workspace_bytes, grad_flat, st);
+}
+
+extern "C" int afx_train_step_mse(afx_ctx* c, int prec, const void* prepared, const afx_render_args* r,
+                                  const float* target, float inv_n, float* grad_flat, void* stream) {
+  if (c && r && r->n_rays == 0) return AFX_OK;
+  int rc = check_render(c, r, "afx_train_step_mse");
+  if (rc) return rc;
+  if (!is_bf16(prec)) return fail(AFX_E_INVALID, "afx_train_step_mse: needs a bf16 precision (use afx_render_forward/backward for f32)");
+  if (!prepared || !target || !grad_flat || !r->workspace) return fail(AFX_E_INVALID, "afx_train_step_mse: null argument");
+  if (256 % s_pad_of(r->n_samples) != 0) return fail(AFX_E_INVALID, "afx_train_step_mse: padded samples per ray (%d) must divide 256", (int)s_pad_of(r->n_samples));
+  ChainArgs a = {};
+  fill_model(c, prec, true, prepared, a);
+  fill_render(r, a);
+  a.sigma = nullptr; a.tau = nullptr;
+  a.fused = 1; a.target = target; a.pixel = r->pixel; a.inv_n = inv_n;
+  return run_backward(c, prec, a, 0, (char*)r->workspace, r->workspace_bytes, grad_flat, (hipStream_t)stream);
 }
 
 extern "C" int afx_mlp_backward(afx_ctx* c, int prec, const void* prepared, const float* pts, int64_t n_pts,

@@ -48,6 +48,11 @@ struct ChainArgs {
   float* stash_e;           // [rows, 2*nq]       encoded inputs
   float* graw;              // [rows]             dL/draw
   int64_t stash_rows;
+  int32_t fused;            // backward kernel computes pixel, MSE gradient and dL/draw itself (train step)
+  const float* target;      // [R] (fused)
+  float* pixel;             // [R] out (fused)
+  float inv_n;              // 1 / global ray count (fused)
+  int32_t debug;            // timing experiments only: bit0 = skip stash stores (results invalid)
 };
 
 struct WgradArgs {

@@ -13,6 +13,7 @@
 //   The first layer (raw world coordinates, +-100) is always split; the output layer (width -> 1) and
 //   the compositing run in fp32 on the VALU.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "afx_internal.h"
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -47,8 +48,8 @@ __device__ __forceinline__ void split_frag(const float* v, u32x4& hi, u32x4& lo)
 // waves per SIMD with <= 256 registers and one column group each: the partner wave's MFMAs cover a wave's
 // epilogue VALU work, barrier and LDS latencies.
 // byte offset of the 16-byte chunk `ch` (8 stash positions) of stash row `r` inside one layer's stash
-template <int F> __device__ __forceinline__ size_t stash_off(int64_t r, int ch) {
-  return ((((size_t)(r >> 5) * (F / 8) + ch) << 5) + (size_t)(r & 31)) << 4;
+template <int F> __device__ __forceinline__ uint32_t stash_off(uint32_t r, int ch) {
+  return ((((r >> 5) * (F / 8) + ch) << 5) + (r & 31)) << 4;      // < 2^32: the host bounds a layer's stash
 }
 
 template <int F, bool X3, bool ENC, bool BWD, int NW>
@@ -75,6 +76,17 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
   const float* aux = sm + (N + 2) * F + 4;
   __syncthreads();
 
+  // slab sizes are fixed by the template parameters (the host lays the prepared buffer out identically)
+  constexpr uint32_t SLAB0 = (NK0 * 2048u + 4095u) / 4096u * 4096u;   // first-layer slab: NK0 x (hi,lo) KiB
+  constexpr uint32_t SLABT = NT * 2048u;                              // one hidden slab part (hi or lo)
+  constexpr uint32_t LOADH = X3 ? 2 * SLABT : SLABT;                  // bytes of a forward hidden slab this kernel reads
+  auto dma = [&](const char* src, char* dst, auto bytes_c) {
+    constexpr uint32_t BYTES = decltype(bytes_c)::value;
+#pragma unroll
+    for (uint32_t off = 0; off < BYTES; off += NW * 1024u)
+      if (off + (uint32_t)wave * 1024u < BYTES)
+        __builtin_amdgcn_global_load_lds(GPTR(src + off + wave * 1024 + lane * 16), LPTR(dst + off + wave * 1024), 16, 0, 0);
+  };
   const int nfwd = NT * (N + 1);
   const int steps_per_tile = nfwd + (BWD ? NT * N : 0);
   int seq = 0;
@@ -88,7 +100,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
   constexpr int SPS = 2 * NCG;
   bool first_step = true;
   auto step_begin = [&]() -> const u32x4* {
-    if (BWD && !first_step) {
+    if (BWD && !first_step && !a.debug) {
       if (SPS == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
     } else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
@@ -97,29 +109,29 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
     bool doload = true;
     if (ni == steps_per_tile) { ni = 0; doload = has_next; }
     if (doload) {
-      const char* src;
-      uint32_t bytes;
-      if (ni < NT) { src = a.stream_fwd + (size_t)ni * a.slab0_bytes; bytes = a.slab0_bytes; }
-      else if (ni < nfwd) { src = a.stream_fwd + (size_t)NT * a.slab0_bytes + (size_t)(ni - NT) * a.slabh_stride; bytes = a.slabh_bytes; }
-      else { src = a.stream_bwd + (size_t)(ni - nfwd) * a.slabt_bytes; bytes = a.slabt_bytes; }
-      glds_copy(src, slot0 + (par ^ 1u) * (size_t)a.slot_bytes, bytes, wave, lane, NW);
+      char* dst = slot0 + (par ^ 1u) * (size_t)a.slot_bytes;
+      if (ni < NT) dma(a.stream_fwd + (size_t)ni * SLAB0, dst, std::integral_constant<uint32_t, SLAB0>{});
+      else if (ni < nfwd) dma(a.stream_fwd + (size_t)NT * SLAB0 + (size_t)(ni - NT) * a.slabh_stride, dst, std::integral_constant<uint32_t, LOADH>{});
+      else dma(a.stream_bwd + (size_t)(ni - nfwd) * SLABT, dst, std::integral_constant<uint32_t, SLABT>{});
     }
     const char* cur = slot0 + par * (size_t)a.slot_bytes;
     par ^= 1u;
     seq = ni;
     return (const u32x4*)cur;
   };
-  glds_copy(a.stream_fwd, slot0, a.slab0_bytes, wave, lane, NW);
+  dma(a.stream_fwd, slot0, std::integral_constant<uint32_t, SLAB0>{});
 
   for (int tile = a.tile0 + blockIdx.x; tile < a.tile1; tile += gridDim.x) {
     has_next = tile + (int)gridDim.x < a.tile1;
-    int64_t n[NCG], m[NCG];
+    int32_t n[NCG];
+    uint32_t m[NCG], so[NCG];           // sample index, stash row, per-lane stash byte offset (chunk 0)
     Sample sp[NCG];
     u32x4 ehi[NCG][NK0], elo[NCG][NK0];
 #pragma unroll
     for (int cg = 0; cg < NCG; ++cg) {
-      n[cg] = (int64_t)tile * TS + wave * (32 * NCG) + cg * 32 + col;
-      m[cg] = (int64_t)(tile - a.tile0) * TS + wave * (32 * NCG) + cg * 32 + col;
+      n[cg] = tile * TS + wave * (32 * NCG) + cg * 32 + col;
+      m[cg] = (uint32_t)(tile - a.tile0) * TS + wave * (32 * NCG) + cg * 32 + col;
+      so[cg] = stash_off<F>(m[cg], hh);
       sp[cg] = make_sample(a, n[cg]);
       // first-layer B fragments: element j of k-step q is encoded input k = 16q + 8*(lane>>5) + j
 #pragma unroll
@@ -132,7 +144,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
         }
         split_frag(e, ehi[cg][q], elo[cg][q]);
         if (BWD) {
-          float* ep = a.stash_e + m[cg] * (16 * NK0) + 16 * q + 8 * hh;
+          float* ep = a.stash_e + (size_t)m[cg] * (16 * NK0) + 16 * q + 8 * hh;
           *(f32x4*)ep = (f32x4){e[0], e[1], e[2], e[3]};
           *(f32x4*)(ep + 4) = (f32x4){e[4], e[5], e[6], e[7]};
         }
@@ -174,11 +186,11 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
 #pragma unroll
           for (int q = 0; q < 4; ++q) nf[s][q] = pack2(v[8 * s + 2 * q], v[8 * s + 2 * q + 1]);
         }
-        if (BWD) {
+        if (BWD && !(a.debug & 1)) {
           // stash position of feature 32t+16s+8(j>>2)+4h+(j&3) is p = 32t+16s+8h+j (bits 2,3 swapped; the
           // weight-gradient kernels undo it with fperm).  Layout [row>>5][p>>3][row&31][8 bf16]: the 64 lanes
           // of this store write one contiguous 1 KiB run (32 samples x 16 B for h = 0, then for h = 1).
-          *(u32x4*)((char*)a.stash_h + (size_t)l * a.stash_rows * (F * 2) + stash_off<F>(m[cg], 4 * t + 2 * s + hh)) = nf[s];
+          *(u32x4*)((char*)a.stash_h + (size_t)l * a.stash_rows * (F * 2) + (so[cg] + (uint32_t)(4 * t + 2 * s) * 512u)) = nf[s];
         }
       }
     };
@@ -187,6 +199,51 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
       const f32x4 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
       return (f32x16){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3],
                       b2[0], b2[1], b2[2], b2[3], b3[0], b3[1], b3[2], b3[3]};
+    };
+
+    // One hidden-layer step: acc[cg] += W_tile . B over all 2*NT k-steps.  A fragments are read from the
+    // slab in groups of G k-steps, two groups in flight (explicit software pipeline; sched_barrier keeps
+    // hipcc from sinking the reads back next to their MFMAs), so LDS latency hides behind >= G MFMAs.
+    auto mma_step = [&](const u32x4* sl, u32x4 (*bh)[NT][2], u32x4 (*bl)[X3 ? NT : 1][2], f32x16* acc) {
+      if (BWD) {      // the backward kernel is register-bound: no explicit read pipeline
+#pragma unroll
+        for (int u = 0; u < 2 * NT; ++u) {
+          const u32x4 ah = sl[u * 64 + lane];
+#pragma unroll
+          for (int cg = 0; cg < NCG; ++cg) acc[cg] = mfma_bf16(ah, bh[cg][u >> 1][u & 1], acc[cg]);
+        }
+        return;
+      }
+      constexpr int G = (X3 || NW == 8) ? 2 : 4;
+      constexpr int NG = 2 * NT / G;
+      u32x4 ab[2][G], al[2][X3 ? G : 1];
+      auto ldgrp = [&](int g, int b) {
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+          ab[b][i] = sl[(g * G + i) * 64 + lane];
+          if (X3) al[b][i] = sl[(2 * NT + g * G + i) * 64 + lane];
+        }
+      };
+      ldgrp(0, 0);
+      if (NG > 1) ldgrp(1, 1);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+          const int u = g * G + i;
+          if (X3) {
+            acc[0] = mfma_bf16(ab[g & 1][i], bh[0][u >> 1][u & 1], acc[0]);
+            acc[0] = mfma_bf16(ab[g & 1][i], bl[0][X3 ? (u >> 1) : 0][u & 1], acc[0]);
+            acc[0] = mfma_bf16(al[g & 1][X3 ? i : 0], bh[0][u >> 1][u & 1], acc[0]);
+          } else {
+#pragma unroll
+            for (int cg = 0; cg < NCG; ++cg) acc[cg] = mfma_bf16(ab[g & 1][i], bh[cg][u >> 1][u & 1], acc[cg]);
+          }
+        }
+        if (g + 2 < NG) ldgrp(g + 2, g & 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     };
 
     // ---------------- layer 0 (always split: hi*hi + hi*lo + lo*hi)
@@ -225,27 +282,35 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
       uint32_t mw[MW * NCG];
 #pragma unroll
       for (int w = 0; w < MW * NCG; ++w) mw[w] = 0;
+      // Forward-only kernels defer the epilogue of tile t-1 into step t (behind that step's MFMAs, which do
+      // not depend on it) so the VALU work overlaps the matrix pipe.  The backward kernel keeps each
+      // epilogue in its own step: its stash stores are what the step's vmcnt(SPS) counts.
+      constexpr bool DEFER = !BWD;
+      f32x16 accp[NCG];
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const u32x4* sl = step_begin();           // hi block [u*64 + lane], then lo block (X3)
         f32x16 acc[NCG];
 #pragma unroll
         for (int cg = 0; cg < NCG; ++cg) acc[cg] = bias_init(l, t);
+        mma_step(sl, hf, hl, acc);
+        if (DEFER) {
+          if (t > 0) {
 #pragma unroll
-        for (int u = 0; u < 2 * NT; ++u) {
-          const u32x4 ah = sl[u * 64 + lane];
-          if (X3) {
-            const u32x4 al = sl[(2 * NT + u) * 64 + lane];
-            acc[0] = mfma_bf16(ah, hf[0][u >> 1][u & 1], acc[0]);
-            acc[0] = mfma_bf16(ah, hl[0][X3 ? (u >> 1) : 0][u & 1], acc[0]);
-            acc[0] = mfma_bf16(al, hf[0][u >> 1][u & 1], acc[0]);
-          } else {
-#pragma unroll
-            for (int cg = 0; cg < NCG; ++cg) acc[cg] = mfma_bf16(ah, hf[cg][u >> 1][u & 1], acc[cg]);
+            for (int cg = 0; cg < NCG; ++cg)
+              epilogue(l, t - 1, accp[cg], cg, nf[cg][t > 0 ? t - 1 : 0], nl[X3 ? cg : 0][X3 && t > 0 ? t - 1 : 0], mw);
           }
-        }
 #pragma unroll
-        for (int cg = 0; cg < NCG; ++cg) epilogue(l, t, acc[cg], cg, nf[cg][t], nl[X3 ? cg : 0][X3 ? t : 0], mw);
+          for (int cg = 0; cg < NCG; ++cg) accp[cg] = acc[cg];
+        } else {
+#pragma unroll
+          for (int cg = 0; cg < NCG; ++cg) epilogue(l, t, acc[cg], cg, nf[cg][t], nl[X3 ? cg : 0][X3 ? t : 0], mw);
+        }
+      }
+      if (DEFER) {
+#pragma unroll
+        for (int cg = 0; cg < NCG; ++cg)
+          epilogue(l, NT - 1, accp[cg], cg, nf[cg][NT - 1], nl[X3 ? cg : 0][X3 ? NT - 1 : 0], mw);
       }
       if (BWD) {
 #pragma unroll
@@ -284,10 +349,38 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
           for (int sh = 16; sh >= 1; sh >>= 1) od += __shfl_xor(od, sh);
           if (lane == 0 && n[cg] < a.n_total) {
             const int gpr = a.s_pad / GROUP;
-            a.od_part[(int64_t)sp[cg].ray * gpr + (int)((n[cg] - (int64_t)sp[cg].ray * a.s_pad) / GROUP)] = od;
+            a.od_part[(int64_t)sp[cg].ray * gpr + (n[cg] - sp[cg].ray * a.s_pad) / GROUP] = od;
           }
+        } else if (a.fused) {
+          // fused training step: every ray lies inside this workgroup tile (host guarantees s_pad | TS).
+          // optical depth of the ray = ordered sum of its 32-sample group partials through LDS
+          float od = tau;
+#pragma unroll
+          for (int sh = 16; sh >= 1; sh >>= 1) od += __shfl_xor(od, sh);
+          float* odb = (float*)(slot0 + 2 * (size_t)a.slot_bytes + (size_t)(N + 1) * MW * NCG * NTH * 4);   // [NW*NCG]
+          if (lane == 0) odb[wave * NCG + cg] = od;
+          g[cg] = sig * (1.f - sig);      // finished below, once all groups of the tile are in LDS
         } else if (sp[cg].live) g[cg] = a.dod[sp[cg].ray] * sp[cg].dt * (sig * (1.f - sig));
       }
+    }
+    if (BWD && a.mode != 0 && a.fused) {
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      const float* odb = (const float*)(slot0 + 2 * (size_t)a.slot_bytes + (size_t)(N + 1) * MW * NCG * NTH * 4);
+      const int gpr = a.s_pad / GROUP;
+#pragma unroll
+      for (int cg = 0; cg < NCG; ++cg) {
+        const int grp = wave * NCG + cg, g0 = grp / gpr * gpr;
+        float od = 0.f;
+        for (int k = 0; k < gpr; ++k) od += odb[g0 + k];
+        const float T = expf(-od);
+        const bool rayok = n[cg] < a.n_total;
+        const float tg = rayok ? a.target[sp[cg].ray] : 0.f;
+        if (lane == 0 && grp == g0 && rayok) a.pixel[sp[cg].ray] = T;
+        // L = mean_r (T_r - target_r)^2 over the GLOBAL batch: dL/dT = 2 (T - target) * inv_n; dT/d(od) = -T
+        const float dod = -T * (2.f * (T - tg) * a.inv_n);
+        g[cg] = sp[cg].live ? dod * sp[cg].dt * g[cg] : 0.f;
+      }
+      asm volatile("s_barrier" ::: "memory");      // odb is rewritten by the next tile
     }
 
     if (BWD) {
@@ -313,12 +406,21 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
             for (int q = 0; q < 4; ++q) dz[cg][t][s][q] = pack2(v[8 * s + 2 * q], v[8 * s + 2 * q + 1]);
         }
       }
+      auto mma_step_plain = [&](const u32x4* sl, u32x4 (*bh)[NT][2], f32x16* acc) {
+#pragma unroll
+        for (int u = 0; u < 2 * NT; ++u) {
+          const u32x4 ah = sl[u * 64 + lane];
+#pragma unroll
+          for (int cg = 0; cg < NCG; ++cg) acc[cg] = mfma_bf16(ah, bh[cg][u >> 1][u & 1], acc[cg]);
+        }
+      };
       auto stash_dz_tile = [&](int l, int t) {
+        if (a.debug & 1) return;
 #pragma unroll
         for (int cg = 0; cg < NCG; ++cg)
 #pragma unroll
           for (int s = 0; s < 2; ++s)
-            *(u32x4*)((char*)a.stash_dz + (size_t)l * a.stash_rows * (F * 2) + stash_off<F>(m[cg], 4 * t + 2 * s + hh)) = dz[cg][t][s];
+            *(u32x4*)((char*)a.stash_dz + (size_t)l * a.stash_rows * (F * 2) + (so[cg] + (uint32_t)(4 * t + 2 * s) * 512u)) = dz[cg][t][s];
       };
       for (int l = N; l >= 1; --l) {
         u32x4 dn[NCG][NT][2];
@@ -329,12 +431,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
           f32x16 acc[NCG];
 #pragma unroll
           for (int cg = 0; cg < NCG; ++cg) acc[cg] = (f32x16){0.f};
-#pragma unroll
-          for (int u = 0; u < 2 * NT; ++u) {
-            const u32x4 ah = sl[u * 64 + lane];
-#pragma unroll
-            for (int cg = 0; cg < NCG; ++cg) acc[cg] = mfma_bf16(ah, dz[cg][u >> 1][u & 1], acc[cg]);
-          }
+          mma_step_plain(sl, dz, acc);
 #pragma unroll
           for (int cg = 0; cg < NCG; ++cg) {
             const uint32_t bits = mk[(((l - 1) * MW + (t >> 1)) * NCG + cg) * NTH + tid] >> (16 * (t & 1));

@@ -145,7 +145,7 @@ class Engine:
         n = pts.shape[0]
         if d_out.numel() != n:
             raise ValueError("d_out: one value per point expected")
-        full = int(self.lib.afx_query(self.h, _lib.Q_BWD_WORKSPACE_FULL, 0, n, 0))
+        full = int(self.lib.afx_query(self.h, _lib.Q_BWD_WORKSPACE_FULL, 0, n, _lib.PREC[prec]))
         ws = self._workspace(min(full, self.max_workspace_bytes), dev)
         _lib.check(self.lib.afx_mlp_backward(self.h, _lib.PREC[prec], _ptr(prepared), _ptr(pts), n, _ptr(d_out),
                                              _ptr(grad_flat), _ptr(ws), ws.numel(), self._stream(dev)),
@@ -216,12 +216,30 @@ class Engine:
         pixel = _f32(pixel, "pixel", dev)
         d_pixel = _f32(d_pixel, "d_pixel", dev)
         a, keep = self._render_args(spec, dev, pixel)
-        full = int(self.lib.afx_query(self.h, _lib.Q_BWD_WORKSPACE_FULL, spec.n_rays, spec.n_samples, 0))
+        full = int(self.lib.afx_query(self.h, _lib.Q_BWD_WORKSPACE_FULL, spec.n_rays, spec.n_samples, _lib.PREC[prec]))
         ws = self._workspace(min(full, self.max_workspace_bytes), dev)
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
         _lib.check(self.lib.afx_render_backward(self.h, _lib.PREC[prec], _ptr(prepared), C.byref(a), _ptr(d_pixel),
                                                 _ptr(grad_flat), self._stream(dev)), "afx_render_backward")
         del keep
+
+
+    def train_step_mse(self, prepared, spec: RenderSpec, target, inv_n: float, grad_flat, prec: str):
+        """Fused forward + MSE + backward (afx_train_step_mse); returns the rendered pixels."""
+        dev = prepared.device
+        target = _f32(target, "target", dev)
+        if target.numel() != spec.n_rays:
+            raise ValueError("target: one value per ray expected")
+        pixel = torch.empty(spec.n_rays, dtype=torch.float32, device=dev)
+        a, keep = self._render_args(spec, dev, pixel)
+        full = int(self.lib.afx_query(self.h, _lib.Q_BWD_WORKSPACE_FULL, 0, spec.n_rays * ((spec.n_samples + 31) // 32 * 32),
+                                      _lib.PREC[prec]))
+        ws = self._workspace(min(full, self.max_workspace_bytes), dev)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+        _lib.check(self.lib.afx_train_step_mse(self.h, _lib.PREC[prec], _ptr(prepared), C.byref(a), _ptr(target),
+                                               float(inv_n), _ptr(grad_flat), self._stream(dev)), "afx_train_step_mse")
+        del keep
+        return pixel
 
 
 # ---- stand-alone compositing / sampling kernels (no model) -----------------------------------

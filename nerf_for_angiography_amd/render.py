@@ -113,6 +113,42 @@ def render_projection(model, poses, width: int, height: int, focal: float, depth
     return render_spec(spec, model, want_aux)
 
 
+def train_step_mse(model, spec: RenderSpec, target: torch.Tensor, n_global: Optional[int] = None):
+    """One fused training pass: render `spec`, L = mean over the (global) batch of (pixel - target)^2, backward.
+
+    Replaces `pred = render(...); loss = mse_loss(pred, target); loss.backward()` (nerf/run_nerf_acc.py:287-306):
+    the gradients are ACCUMULATED into `.grad` of the model's Linear parameters exactly as loss.backward() would,
+    so `optimizer.zero_grad(); train_step_mse(...); optimizer.step()` is the training iteration.  The forward pass
+    is the backward kernel's own recompute (bf16), nothing is rendered twice.  Returns (loss, pixels), detached.
+    n_global: total rays of the step across all ranks (default: this batch) - the mean is over that count."""
+    _check_model(model)
+    if model.precision == "f32":
+        raise NotImplementedError("train_step_mse needs a bf16 precision; with 'f32' use render + autograd")
+    n = int(n_global) if n_global else int(spec.n_rays)
+    flat_grad = torch.zeros(model.engine.param_count, dtype=torch.float32, device=model.flat_params.device)
+    pixel = model.engine.train_step_mse(model._prepared(), spec, target, 1.0 / n, flat_grad, model.precision)
+    if _grad_hook is not None:
+        _grad_hook(flat_grad)
+    for p, g in zip(model._hip_params(), model._split_grad(flat_grad)):
+        if p.grad is None:
+            p.grad = g
+        else:
+            p.grad.add_(g)
+    loss = torch.nn.functional.mse_loss(pixel, target) if n == spec.n_rays else ((pixel - target) ** 2).sum() / n
+    return loss, pixel
+
+
+def projection_spec(poses, width, height, focal, depth_samples_per_ray, near_thresh, far_thresh, ray_ids=None,
+                    ray_id0=0, n_rays=None) -> RenderSpec:
+    """RenderSpec for rays generated in-kernel from C-arm poses ('acc' convention)."""
+    poses = poses[:, :3, :].contiguous()
+    if n_rays is None:
+        n_rays = ray_ids.numel() if ray_ids is not None else poses.shape[0] * width * height - ray_id0
+    return RenderSpec(n_rays=int(n_rays), n_samples=int(depth_samples_per_ray), poses=poses, ray_ids=ray_ids,
+                      ray_id0=int(ray_id0), width=int(width), height=int(height), focal=float(focal), mode="acc",
+                      t_near=float(near_thresh), t_far=float(far_thresh))
+
+
 def density_grid(model, outside: float, n: int) -> torch.Tensor:
     """sigma on meshgrid(t,t,t), t = linspace(-outside, outside, n+1), numpy 'xy' indexing as upstream
     (visualization/visualization.py:100-102,209-229): grid[i,j,k] = sigma(t[j], t[i], t[k])."""
