@@ -43,7 +43,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--precision", default=os.environ.get("AFX_BENCH_PRECISION", "f32"))
+    ap.add_argument("--precision", default=os.environ.get("AFX_BENCH_PRECISION", "bf16"), choices=["f32", "bf16x3", "bf16"])
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--samples", type=int, default=128)
     ap.add_argument("--layers", type=int, default=8)
@@ -139,14 +139,28 @@ def main():
     peak = PEAK_TFLOPS[args.precision]
     dom_ms, dom_n = prof["chain_bwd"]
     per_launch_samples = samples_per_step * args.steps / max(dom_n, 1)
-    achieved = (dgrad_f * per_launch_samples) / (dom_ms / max(dom_n, 1) * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-    roofline = {"bound": "mfma", "kernel": "k_chain<bwd> (forward recompute + input-gradient chain + stash)",
+    avg_s = dom_ms / max(dom_n, 1) * 1e-3
+    # k_chain<bwd> does the forward (fused: it IS the step's forward pass; unfused: a recompute that is not
+    # counted) and the input-gradient chain.  Algorithmic FLOPs per sample of that launch:
+    alg = (fwd_f + dgrad_f) if fused else dgrad_f
+    achieved = alg * per_launch_samples / avg_s / 1e12 if dom_ms > 0 else 0.0
+    esz = 4 if args.precision == "f32" else 2
+    stash_bytes = 2 * (args.layers + 1) * args.width * esz          # H_l and dZ_l written per sample by that launch
+    roofline = {"bound": "mfma", "kernel": "k_chain<bwd>: forward + Beer-Lambert + input-gradient chain + stash of H_l, dZ_l",
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                "traffic": None, "launches": dom_n, "avg_launch_ms": round(dom_ms / max(dom_n, 1), 3),
-                "algorithmic_flop_per_sample": dgrad_f,
-                "executed_frac_incl_recompute": round(achieved * (fwd_f + dgrad_f) / dgrad_f / peak, 4),
+                "traffic": None, "launches": dom_n, "avg_launch_ms": round(avg_s * 1e3, 3),
+                "algorithmic_flop_per_sample": alg,
+                "hbm_write_GBps_algorithmic": round(stash_bytes * per_launch_samples / avg_s / 1e9, 1),
                 "kernel_ms_per_step": {k: round(v[0] / args.steps, 2) for k, v in prof.items()},
-                "step_tflops_algorithmic": round((fwd_f + dgrad_f + wgrad_f) * value / world / 1e12, 2)}
+                "wgrad_hbm_read_GBps_algorithmic": round(stash_bytes * samples_per_step / max(prof["wgrad"][0] / args.steps * 1e-3, 1e-9) / 1e9, 1),
+                "step_tflops_algorithmic": round((fwd_f + dgrad_f + wgrad_f) * value / world / 1e12, 2),
+                "step_frac_of_peak": round((fwd_f + dgrad_f + wgrad_f) * value / world / 1e12 / peak, 4)}
+    traffic_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(traffic_file):      # HBM bytes per launch from the committed rocprofv3 --pmc passes
+        try:
+            roofline["traffic"] = json.load(open(traffic_file)).get(args.precision)
+        except Exception:
+            pass
 
     result = {"metric": "ray-samples/sec (fwd+bwd)", "value": round(value, 1), "unit": "ray-samples/s",
               "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -176,8 +190,14 @@ def cpu_leg(model, args, pose, target, W, H, focal, near, far, S, device, render
     tgt = target.cpu()[pick]
     cfg = dict(num_early_layers=args.layers, num_filters=args.width)
     params = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    pix_by_prec = {}
+    keep = model.precision
     with torch.no_grad():
-        pix_gpu = render_rays(model, o.to(device), d.to(device), S, near, far, mode="acc").rgb_map.cpu()
+        for prec in dict.fromkeys([keep, "bf16x3", "bf16"]):
+            model.precision = prec
+            pix_by_prec[prec] = render_rays(model, o.to(device), d.to(device), S, near, far, mode="acc").rgb_map.cpu()
+    model.precision = keep
+    pix_gpu = pix_by_prec[keep]
     try:
         ncpu = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -205,7 +225,9 @@ def cpu_leg(model, args, pose, target, W, H, focal, near, far, S, device, render
                              "sample": f"{args.cpu_rays} rays x {S} samples of the same projection, {args.layers}x{args.width} MLP, "
                                        "fp32 PyTorch-CPU oracle, fwd+bwd+Adam, best of 2 timed steps after 1 warm-up"},
             "parity_vs_cpu_oracle": {"rays": args.cpu_rays, "rel_l2": rel,
-                                     "psnr_db": round(-10 * np.log10(max(mse, 1e-30)), 2)}}
+                                     "psnr_db": round(-10 * np.log10(max(mse, 1e-30)), 2),
+                                     "rel_l2_by_precision": {k: float((v - pix_cpu).norm() / pix_cpu.norm())
+                                                             for k, v in pix_by_prec.items()}}}
 
 
 if __name__ == "__main__":

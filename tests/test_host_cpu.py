@@ -1,0 +1,289 @@
+"""CPU-only tests: the C-ABI library loads and exports what include/afx.h declares, host-side logic
+(argument validation, layouts, CPPN mirror, helper mirrors) and the 2-rank gloo data-parallel path.
+No kernel is launched here."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, rel_l2
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def model_def(layers, width, pos_enc="none", act="relu", late=0, **kw):
+    d = dict(num_early_layers=layers, num_late_layers=late, num_filters=width, num_input_channels=3,
+             num_output_channels=1, num_input_channels_views=0, use_bias=True, pos_enc=pos_enc, pos_enc_basis=5,
+             act_func=act, fourier_sigma=5, num_img=1, device=torch.device("cpu"))
+    if act == "sine":
+        d["sine_weights"] = 15
+    d.update(kw)
+    return d
+
+
+# ---------------------------------------------------------------- C-ABI surface
+def header_functions():
+    txt = open(os.path.join(ROOT, "include", "afx.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(afx_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from nerf_for_angiography_amd import _lib
+    declared = header_functions()
+    assert len(declared) >= 17
+    assert sorted(_lib.exported_symbols()) == declared          # ctypes table == header
+    lib = _lib.load()                                            # raises if a symbol is missing
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    for name in declared:
+        assert re.search(rf"\bT {name}\b", nm), name
+        assert getattr(lib, name) is not None
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    from nerf_for_angiography_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.AfxError, match="not built"):
+        _lib.load()
+
+
+def test_context_queries_and_validation_without_gpu():
+    from nerf_for_angiography_amd import _lib
+    lib = _lib.load()
+    h = C.c_void_p()
+    d = _lib.ModelDesc(3, 0, 0, 256, 8)
+    assert lib.afx_create(C.byref(d), C.byref(h)) == 0
+    assert lib.afx_query(h, _lib.Q_PARAM_COUNT, 0, 0, 0) == 527617      # 8x256, 3 inputs (Linear layers only)
+    assert lib.afx_query(h, _lib.Q_K0, 0, 0, 0) == 3
+    wo, bo, r, c = C.c_int64(), C.c_int64(), C.c_int32(), C.c_int32()
+    assert lib.afx_param_layout(h, 9, C.byref(wo), C.byref(bo), C.byref(r), C.byref(c)) == 0
+    assert (r.value, c.value, bo.value - wo.value) == (1, 256, 256)
+    assert lib.afx_param_layout(h, 10, None, None, None, None) < 0
+    for prec in (0, 1, 2):
+        assert lib.afx_query(h, _lib.Q_PREPARED_BYTES, prec, 0, 0) > 1 << 20
+    full = lib.afx_query(h, _lib.Q_BWD_WORKSPACE_FULL, 4096, 128, 2)
+    assert full > lib.afx_query(h, _lib.Q_BWD_WORKSPACE_MIN, 4096, 0, 2) > 0
+    lib.afx_destroy(h)
+    # bad descriptors are refused with a message
+    for bad in (_lib.ModelDesc(2, 0, 0, 256, 8), _lib.ModelDesc(3, 0, 0, 100, 8), _lib.ModelDesc(3, 1, 0, 64, 4),
+                _lib.ModelDesc(3, 0, 0, 64, 0)):
+        assert lib.afx_create(C.byref(bad), C.byref(h)) == -1
+        assert lib.afx_last_error()
+    d = _lib.ModelDesc(3, 1, 5, 64, 4)
+    assert lib.afx_create(C.byref(d), C.byref(h)) == 0
+    assert lib.afx_query(h, _lib.Q_K0, 0, 0, 0) == 33
+    assert lib.afx_query(h, _lib.Q_PARAM_COUNT, 0, 0, 0) == 64 * 33 + 64 + 4 * (64 * 64 + 64) + 65
+    # null / malformed call arguments come back as error codes, not crashes
+    args = _lib.RenderArgs()
+    assert lib.afx_render_forward(h, 0, None, C.byref(args), None) == 0          # zero rays: nothing to do
+    args.n_rays, args.n_samples = 8, 32
+    assert lib.afx_render_forward(h, 0, None, C.byref(args), None) == -1
+    assert b"origins" in lib.afx_last_error()
+    assert lib.afx_mlp_infer(h, 7, None, None, 4, None, 0, None) == -1
+    lib.afx_destroy(h)
+
+
+def test_fused_path_refuses_cpu_tensors():
+    from nerf_for_angiography_amd.model.CPPN import CPPN
+    from nerf_for_angiography_amd.render import render_rays
+    from nerf_for_angiography_amd._lib import AfxError
+    m = CPPN(model_def(4, 64))
+    with pytest.raises(AfxError, match="no CPU fallback"):
+        render_rays(m, torch.zeros(4, 3), torch.zeros(4, 3), 32, 0.0, 1.0)
+    with pytest.raises(NotImplementedError):
+        render_rays(CPPN(model_def(4, 64, act="tanh")), torch.zeros(4, 3), torch.zeros(4, 3), 32, 0.0, 1.0)
+
+
+# ---------------------------------------------------------------- CPPN mirror
+CASES = {"none_relu_4x64": model_def(4, 64), "none_tanh_4x64": model_def(4, 64, act="tanh"),
+         "none_sine_4x64": model_def(4, 64, act="sine"), "none_relu_4x64_late4": model_def(4, 64, late=4),
+         "fourier_relu_4x64": model_def(4, 64, pos_enc="fourier"), "none_relu_8x256": model_def(8, 256)}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_cppn_mirror_state_dict_and_forward(golden, name):
+    """Same state-dict keys/shapes as the reference and, through PyTorch operators on the host, same outputs."""
+    from nerf_for_angiography_amd.model.CPPN import CPPN
+    g = golden("g4_cppn_" + name)
+    ref_sd = {k[4:]: v for k, v in g.items() if k.startswith("sd__")}
+    m = CPPN(CASES[name])
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(ref_sd.keys())
+    assert all(tuple(sd[k].shape) == ref_sd[k].shape for k in sd)
+    m.load_state_dict({k: T(v) for k, v in ref_sd.items()})
+    with torch.no_grad():
+        y = m(T(g["x"]))
+    assert rel_l2(y.numpy(), g["y"]) < 2e-6
+
+
+def test_cppn_barf_schedule_is_literal(golden):
+    from nerf_for_angiography_amd.model.CPPN import CPPN
+    g = golden("g4_cppn_barf_relu_4x64")
+    m = CPPN(model_def(4, 64, pos_enc="barf"))
+    m.load_state_dict({k[4:]: T(v) for k, v in g.items() if k.startswith("sd__")})
+    for a in (0.0, 1.5, 2.5, 5.0):
+        m.update_barf_alpha(a, "pts")
+        assert m.barf_alpha == a
+        assert np.array_equal(m.barf_weights.detach().numpy(), g[f"w_alpha{a}"])
+        with torch.no_grad():
+            assert rel_l2(m(T(g["x"])).numpy(), g[f"y_alpha{a}"]) < 2e-6
+
+
+def test_cppn_parameters_are_views_of_one_flat_buffer(tmp_path):
+    from nerf_for_angiography_amd.model.CPPN import CPPN
+    m = CPPN(model_def(4, 64))
+    assert m.fused and m.flat_params.numel() == 3 * 64 + 64 + 4 * (64 * 64 + 64) + 65
+    lins = [x for x in m.early_pts_layers if isinstance(x, torch.nn.Linear)] + [m.output_linear[0]]
+    base = m.flat_params.data_ptr()
+    off = 0
+    for lin in lins:
+        assert lin.weight.data_ptr() == base + 4 * off
+        off += lin.weight.numel()
+        assert lin.bias.data_ptr() == base + 4 * off
+        off += lin.bias.numel()
+    # an optimizer step and load_state_dict write through to the flat buffer and bump the cache key
+    before = m.flat_params.clone()
+    v0 = tuple(p._version for p in m._hip_params())
+    opt = torch.optim.Adam(m.parameters(), lr=1e-2)
+    m(torch.randn(16, 3)).sum().backward()
+    opt.step()
+    assert not torch.equal(before, m.flat_params)
+    assert tuple(p._version for p in m._hip_params()) != v0
+    sd = {k: torch.zeros_like(v) for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    assert float(m.flat_params.abs().max()) == 0.0 and lins[0].weight.data_ptr() == base
+    # checkpoint dictionary layout of CPPN.save
+    path = str(tmp_path / "ckpt.pth")
+    m.save(path, {"epochs": 3})
+    ck = torch.load(path, weights_only=False)
+    assert set(ck) == {"version", "parameters", "training_information", "model"} and ck["version"] == "v0.00"
+    assert list(ck["model"].keys()) == list(m.state_dict().keys())
+
+
+# ---------------------------------------------------------------- helper mirrors on the host
+def test_pose_and_ray_helpers_match_golden(golden):
+    from nerf_for_angiography_amd.phantomdata import proj_helpers as ph
+    from nerf_for_angiography_amd.phantomdata.helpers import get_ray_values, get_depth_values
+    g = golden("g1_pose")
+    for a, mref in zip(g["args"][::7], g["mats"][::7]):
+        np.testing.assert_allclose(ph.source_matrix(g["src_pt"], a[0], a[1], a[2], list(a[3:6])), mref, atol=1e-12)
+    g2 = golden("g2_rays")
+    w, h, f = g2["b_whf"]
+    o, d, mat, ii, jj = get_ray_values(35.0, -20.0, 5.0, np.array([0, 0, f + 200.0]), int(w), int(h), float(f), "cpu",
+                                       np.array([3.0, -2.0, 1.0]))
+    assert np.array_equal(mat, g2["b_pose"]) and ii.shape == (int(h), int(w))
+    np.testing.assert_allclose(d.numpy(), g2["b_d"], atol=1e-15)
+    assert np.array_equal(get_depth_values(float(f) + 100, float(f) + 300, 8, "cpu", stratified=False).numpy(), g2["b_z"])
+
+
+def test_nerf_helpers_host_paths_match_golden(golden):
+    from nerf_for_angiography_amd.nerf import nerf_helpers as nh
+    g3 = golden("g3_stratify")
+    torch.manual_seed(100 + 32)
+    assert np.array_equal(nh.randomize_depth(T(g3["z32"]), "cpu").numpy(), g3["out32"])
+    g5 = golden("g5_render")
+    for rk in ("n", "tail", "c2", "c3"):
+        rgb, dep, w, ent, (sig, _) = nh.render_volume_density(T(g5["raw_" + rk]), T(g5["d"]), T(g5["z2"]))
+        for name, got in (("rgb", rgb), ("depth", dep), ("weights", w), ("entropy", ent), ("sigma", sig)):
+            np.testing.assert_allclose(got.numpy(), g5[f"{rk}_z2_{name}"], rtol=2e-6, atol=1e-30)
+    np.testing.assert_allclose(nh.cumprod_exclusive(T(g5["cumprod_in"])).numpy(), g5["cumprod_out"], rtol=1e-7)
+    g7 = golden("g7_sample_pdf")
+    out = nh.sample_pdf(T(g7["a_bins"]), T(g7["a_w"]), 16, "cpu", u=T(g7["a_u"]))
+    assert rel_l2(out.numpy(), g7["a_out"]) < 1e-7
+    assert [b.shape[0] for b in nh.get_minibatches(torch.zeros(10, 3), 4)] == [4, 4, 2]
+
+
+def test_fine_sampling_restated_call_runs_on_host(golden):
+    """The upstream fine_sampling cannot run; the restated one does and returns 3 outputs."""
+    from nerf_for_angiography_amd.nerf import nerf_helpers as nh
+    from nerf_for_angiography_amd.model.CPPN import CPPN
+    from oracle import angio_oracle as orc
+    torch.manual_seed(0)
+    m = CPPN(model_def(4, 64))
+    r, s, nf = 12, 16, 8
+    o = torch.tensor([[0.0, 0.0, 1500.0]]).repeat(r, 1)
+    d = torch.nn.functional.normalize(torch.randn(r, 3) * 0.02 + torch.tensor([0, 0, -1.0]), dim=-1)
+    z = torch.linspace(1400.0, 1600.0, s)
+    w = torch.rand(r, s)
+    u = torch.rand(r, nf)
+    with torch.no_grad():
+        rgb, dep, ent = nh.fine_sampling(z, w, o, d, m, None, nf, 4096, u=u)
+    assert rgb.shape == (r,) and dep.shape == (r,) and ent.shape == (r,)
+    zf = orc.fine_depths(z, w, u, r)
+    assert zf.shape == (r, s + nf) and float((zf[:, 1:] - zf[:, :-1]).min()) >= 0
+
+
+def test_acc_helpers_host_paths():
+    from nerf_for_angiography_amd.nerf import nerf_helpers_acc as na
+    from oracle import angio_oracle as orc
+    o, d = torch.zeros(5, 3), torch.ones(5, 3)
+    ri, ts, te = na.acc_ray_marching(None, None, None, o, d, 16, 1400.0, 1600.0)
+    ri_o, ts_o, te_o = orc.march_uniform(1400.0, 1600.0, 16, 5)
+    assert torch.equal(ri.long(), ri_o) and torch.equal(ts, ts_o) and torch.equal(te, te_o)
+    pred = torch.randn(80, 1)
+    pix, ent = na.acc_render_volume_density(pred, ri, ts, te, 5, 16)
+    assert ent is None
+    assert rel_l2(pix.numpy(), orc.acc_render_volume_density(pred, ri, ts, te, 5).numpy()) < 1e-6
+    with pytest.raises(NotImplementedError):
+        na.acc_ray_marching(None, object(), None, o, d, 16, 0.0, 1.0)
+    assert na.acc_update_n_step(None, None, 0) is None
+
+
+def test_bench_flop_model():
+    sys.path.insert(0, ROOT)
+    import bench
+    fwd, dgrad, wgrad = bench.flops_per_sample(256, 8)
+    assert (fwd, fwd + dgrad + wgrad) == (1050624, 3150336)
+    fwd, dgrad, wgrad = bench.flops_per_sample(64, 4)
+    assert fwd + dgrad + wgrad == 99456
+
+
+# ---------------------------------------------------------------- data-parallel path on 2 gloo ranks
+def _dp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    from nerf_for_angiography_amd import dist as afx_dist
+    from nerf_for_angiography_amd import render
+    from nerf_for_angiography_amd.model.CPPN import CPPN
+    r, w, dev = afx_dist.init_from_env("gloo")
+    torch.manual_seed(rank)                       # different weights per rank until the broadcast
+    m = CPPN(model_def(4, 64))
+    afx_dist.broadcast_parameters(m)
+    flat0 = m.flat_params.clone()
+    sync = afx_dist.GradSync().install()
+    assert render._grad_hook is sync
+    g = torch.full((m.flat_params.numel(),), float(rank + 1))
+    render._grad_hook(g)                          # what _RenderFn.backward / train_step_mse call
+    start, count = afx_dist.shard(10, r, w)
+    q.put((rank, flat0[:8].tolist(), float(g[0]), start, count))
+    afx_dist.GradSync.uninstall()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_grad_sync_and_sharding():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + os.getpid() % 300
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, w0, g0, s0, c0), (r1, w1, g1, s1, c1) = res
+    assert w0 == w1                                # rank 0's weights everywhere
+    assert g0 == g1 == 1.5                         # mean of the per-rank gradients (1 and 2)
+    assert (s0, c0, s1, c1) == (0, 5, 5, 5)
+    from nerf_for_angiography_amd.dist import shard
+    assert [shard(10, r, 4) for r in range(4)] == [(0, 3), (3, 3), (6, 2), (8, 2)]
