@@ -437,3 +437,139 @@ def test_argument_validation():
     # empty batch
     out = render_rays(m, o[:0], o[:0], 32, 0.0, 1.0)
     assert out.rgb_map.shape == (0,)
+
+
+# ------------------------------------------------------------------------------------------------
+# Encoded inputs (BARF) through forward AND backward; hierarchical pipeline; full-size properties; graphs
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("prec", ["f32", "bf16x3", "bf16"])
+def test_barf_backward_vs_oracle(prec):
+    """K0 = 33 encoded inputs: first-layer MFMA k-steps, encoded-input stash and first-layer weight gradient."""
+    from oracle import angio_oracle as orc
+    from nerf_for_angiography_amd.render import render_rays
+    torch.manual_seed(11)
+    m = make_model(4, 64, "barf", precision=prec)
+    m.update_barf_alpha(3.5, "pts")
+    with torch.no_grad():
+        m.output_linear[0].weight.mul_(4.0)
+        m.output_linear[0].bias.fill_(-4.0)
+    r, s = 300, 40
+    o = torch.tensor([[0.0, 0.0, 1.5]]).repeat(r, 1) + torch.randn(r, 3) * 0.01      # unit-scale scene: sin/cos args stay small
+    d = torch.nn.functional.normalize(torch.randn(r, 3) * 0.2 + torch.tensor([0, 0, -1.0]), dim=-1)
+    tgt = torch.rand(r)
+    cfg = dict(num_early_layers=4, num_filters=64, pos_enc="barf", pos_enc_basis=5)
+    params = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    pix_c, _, grads_c = orc.loss_and_grads(o, d, tgt, cfg, params, near=0.5, far=2.5, n_samples=s, convention="acc")
+    out = render_rays(m, o.to(DEV), d.to(DEV), s, 0.5, 2.5, mode="acc")
+    torch.nn.functional.mse_loss(out.rgb_map, tgt.to(DEV)).backward()
+    assert rel_l2(out.rgb_map.detach().cpu().numpy(), pix_c.numpy()) < TOL[prec]["pix"]
+    got = _grads_by_name(m)
+    assert set(grads_c) <= set(got)
+    for k, v in grads_c.items():
+        assert rel_l2(got[k], v.numpy()) < TOL[prec]["grad"], k
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_hierarchical_coarse_fine_vs_oracle(prec):
+    """Config-C3 style pipeline: coarse dense render -> weights -> sample_pdf/merge (afx_fine_depths) -> fine render
+    with per-ray depths, against the oracle's composition of the same reference pieces."""
+    from oracle import angio_oracle as orc
+    from nerf_for_angiography_amd.render import render_rays
+    from nerf_for_angiography_amd.nerf.nerf_helpers import fine_sampling
+    torch.manual_seed(13)
+    m = make_model(4, 64, precision=prec)
+    with torch.no_grad():
+        m.output_linear[0].weight.mul_(8.0)
+        m.output_linear[0].bias.fill_(-6.0)
+    r, sc, nf = 200, 32, 16
+    o = torch.tensor([[0.0, 0.0, 1500.0]]).repeat(r, 1)
+    d = torch.nn.functional.normalize(torch.randn(r, 3) * 0.03 + torch.tensor([0, 0, -1.0]), dim=-1) * 1.001
+    z = orc.depth_values(1400.0, 1600.0, sc)
+    u = torch.rand(r, nf)
+    cfg = dict(num_early_layers=4, num_filters=64)
+    params = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    fn = lambda p: orc.cppn_forward(p, cfg, params)
+    raw_c = orc.get_predictions(fn, orc.points_dense(o, d, z).reshape(-1, 3), 8192).reshape(r, sc, 1)
+    _, _, w_c, _, _ = orc.render_volume_density(raw_c, d, z)
+    zf_c = orc.fine_depths(z, w_c, u, r)
+    raw_f = orc.get_predictions(fn, orc.points_dense(o, d, zf_c).reshape(-1, 3), 8192).reshape(r, sc + nf, 1)
+    _, dep_c, wf_c, ent_c, _ = orc.render_volume_density(raw_f, d, zf_c)
+    with torch.no_grad():
+        coarse = render_rays(m, o.to(DEV), d.to(DEV), mode="dense", z=z.to(DEV), want_aux=True)
+        assert rel_l2(coarse.weights.cpu().numpy(), w_c.numpy()) < 10 * TOL[prec]["pix"]
+        rgb_f, dep_f, ent_f = fine_sampling(z.to(DEV), coarse.weights, o.to(DEV), d.to(DEV), m, None, nf, 8192, u=u.to(DEV))
+    assert float(rgb_f.abs().max()) == 0.0                      # D3: the 1e10 tail zeroes the projection
+    assert rel_l2(dep_f.cpu().numpy(), dep_c.numpy()) < 1e-4
+    assert rel_l2(ent_f.cpu().numpy(), ent_c.numpy()) < 1e-3
+
+
+def test_full_size_projection_properties():
+    """BASELINE size (512x512 rays x 128 samples, 8x256): properties that need no CPU oracle —
+    two independent arithmetic paths (exact-fp32 MFMA vs split-bf16) agree to the parity bar on every pixel,
+    pixels are transmittances in [0,1], in-kernel ray generation == array rays, chunked backward == fused
+    train step, and the result does not depend on how the workspace chunks the rays."""
+    from nerf_for_angiography_amd.render import render_projection, render_rays, train_step_mse, projection_spec
+    from nerf_for_angiography_amd.phantomdata.helpers import get_ray_values
+    torch.manual_seed(0)
+    W = 512
+    m = make_model(8, 256, precision="bf16x3")
+    with torch.no_grad():
+        m.output_linear[0].weight.mul_(4.0)
+        m.output_linear[0].bias.fill_(-5.0)
+    o, d, m44, _, _ = get_ray_values(24.0, 8.0, 0.0, np.array([0, 0, 1500.0]), W, W, 13.0 * W, DEV)
+    poses = torch.from_numpy(m44[None]).to(DEV)
+    with torch.no_grad():
+        a = render_projection(m, poses, W, W, 13.0 * W, 128, 1400.0, 1600.0).rgb_map
+        b = render_rays(m, o.reshape(-1, 3).float().contiguous(), d.reshape(-1, 3).float().contiguous(), 128, 1400.0, 1600.0).rgb_map
+        m.precision = "f32"
+        c = render_projection(m, poses, W, W, 13.0 * W, 128, 1400.0, 1600.0).rgb_map
+    assert a.shape == (W * W,) and torch.equal(a, b)
+    assert float(a.min()) >= 0.0 and float(a.max()) <= 1.0 and 1e-3 < float(a.std())
+    assert rel_l2(a.cpu().numpy(), c.cpu().numpy()) < 1e-4
+    assert float((a - c).abs().max()) < 2e-4
+    # training step: fused vs autograd path, and chunking invariance (3 chunks vs 1)
+    m.precision = "bf16"
+    tgt = torch.rand(W * W, device=DEV)
+    spec = projection_spec(poses, W, W, 13.0 * W, 128, 1400.0, 1600.0)
+    m.zero_grad()
+    loss1, pix1 = train_step_mse(m, spec, tgt)
+    g1 = _grads_by_name(m)
+    m.engine.max_workspace_bytes = 9 << 30
+    m.engine._ws = None
+    m.zero_grad()
+    loss2, pix2 = train_step_mse(m, spec, tgt)
+    g2 = _grads_by_name(m)
+    assert torch.equal(pix1, pix2)
+    for k in g1:
+        assert rel_l2(g2[k], g1[k]) < 1e-5, k
+    assert rel_l2(pix1.cpu().numpy(), c.cpu().numpy()) < TOL["bf16"]["pix"]
+
+
+def test_hip_graph_capture_of_the_render_and_train_step(golden):
+    """The C-ABI allocates nothing and never synchronises: a fused forward and a fused train step can be
+    captured into a HIP graph and replayed (BASELINE config 5 asks for a hipGraph-captured render step)."""
+    from nerf_for_angiography_amd.engine import RenderSpec
+    g, m, near, far, s = _c1(golden, "bf16")
+    o, d, tgt = T(g["o"]), T(g["d"]), T(g["target"])
+    spec = RenderSpec(n_rays=o.shape[0], n_samples=s, origins=o, dirs=d, mode="acc", t_near=near, t_far=far)
+    eng = m.engine
+    prepared = m._prepared()
+    grad_eager = torch.zeros(eng.param_count, device=DEV)
+    pix_eager = eng.train_step_mse(prepared, spec, tgt, 1.0 / o.shape[0], grad_eager, "bf16")      # also sizes the workspace
+    fwd_eager, _, _ = eng.render_forward(prepared, spec, "bf16")
+    torch.cuda.synchronize()
+    grad_g = torch.zeros(eng.param_count, device=DEV)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            grad_g.zero_()
+            pix_g = eng.train_step_mse(prepared, spec, tgt, 1.0 / o.shape[0], grad_g, "bf16")
+    torch.cuda.current_stream().wait_stream(side)
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(pix_g, pix_eager)
+    assert torch.equal(grad_g, grad_eager)
+    assert rel_l2(fwd_eager.cpu().numpy(), pix_eager.cpu().numpy()) < 1e-6
