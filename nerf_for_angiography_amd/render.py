@@ -113,6 +113,10 @@ def render_projection(model, poses, width: int, height: int, focal: float, depth
     return render_spec(spec, model, want_aux)
 
 
+def _as_f32(t, device):
+    return t.to(device=device, dtype=torch.float32)
+
+
 def train_step_mse(model, spec: RenderSpec, target: torch.Tensor, n_global: Optional[int] = None):
     """One fused training pass: render `spec`, L = mean over the (global) batch of (pixel - target)^2, backward.
 
@@ -126,7 +130,15 @@ def train_step_mse(model, spec: RenderSpec, target: torch.Tensor, n_global: Opti
         raise NotImplementedError("train_step_mse needs a bf16 precision; with 'f32' use render + autograd")
     n = int(n_global) if n_global else int(spec.n_rays)
     flat_grad = torch.zeros(model.engine.param_count, dtype=torch.float32, device=model.flat_params.device)
-    pixel = model.engine.train_step_mse(model._prepared(), spec, target, 1.0 / n, flat_grad, model.precision)
+    s_pad = (spec.n_samples + 31) // 32 * 32
+    if 256 % s_pad == 0:
+        pixel = model.engine.train_step_mse(model._prepared(), spec, target, 1.0 / n, flat_grad, model.precision)
+    else:
+        # a ray would straddle workgroup tiles (e.g. the reference's 300 samples/ray): same arithmetic in two
+        # launches - forward, then the backward kernel with dL/dpixel = 2 (pixel - target) / n
+        pixel, _, _ = model.engine.render_forward(model._prepared(), spec, model.precision)
+        d_pixel = (pixel - _as_f32(target, pixel.device)) * (2.0 / n)
+        model.engine.render_backward(model._prepared(), spec, pixel, d_pixel, flat_grad, model.precision)
     if _grad_hook is not None:
         _grad_hook(flat_grad)
     for p, g in zip(model._hip_params(), model._split_grad(flat_grad)):

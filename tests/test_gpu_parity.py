@@ -573,3 +573,27 @@ def test_hip_graph_capture_of_the_render_and_train_step(golden):
     assert torch.equal(pix_g, pix_eager)
     assert torch.equal(grad_g, grad_eager)
     assert rel_l2(fwd_eager.cpu().numpy(), pix_eager.cpu().numpy()) < 1e-6
+
+
+def test_training_driver_runs_and_checkpoints(tmp_path):
+    """Mirror of nerf/run_nerf_acc.py on a tiny synthetic dataset: loss goes down, the best checkpoint has the
+    reference's dictionary layout and reloads into a fresh CPPN; 300 samples/ray (the reference's setting,
+    not a divisor of the tile) exercises the two-launch train step."""
+    from nerf_for_angiography_amd.nerf.run_nerf_acc import main
+    from nerf_for_angiography_amd.model.CPPN import CPPN
+    out = main(["--synthetic", "--img_size", "20", "--number_angles", "1", "--limited_size", "90", "--n_iters", "120",
+                "--display_every", "60", "--sample_size", "16", "--depth_samples", "300", "--num_layers", "4",
+                "--num_hidden_units", "64", "--sampling_strategy", "segmentation", "--log_dir", str(tmp_path / "run")])
+    h = out["history"]
+    assert [r["iter"] for r in h] == [0, 60, 120]
+    assert h[-1]["train_loss"] < h[0]["train_loss"]
+    assert all(np.isfinite(r["test_psnr"]) for r in h)
+    ck = torch.load(str(tmp_path / "run" / "coarsemodel.pth"), weights_only=False)
+    assert set(ck) == {"version", "parameters", "training_information", "model"}
+    m2 = CPPN(ck["parameters"]).to(DEV)
+    m2.load_state_dict(ck["model"])
+    x = torch.randn(64, 3, device=DEV) * 50
+    if ck["training_information"]["epochs"] == 120:
+        with torch.no_grad():
+            assert torch.equal(m2(x), out["model"](x))
+    assert len((tmp_path / "run" / "train_log.jsonl").read_text().splitlines()) == 3

@@ -287,3 +287,42 @@ def test_two_rank_gloo_grad_sync_and_sharding():
     assert (s0, c0, s1, c1) == (0, 5, 5, 5)
     from nerf_for_angiography_amd.dist import shard
     assert [shard(10, r, 4) for r in range(4)] == [(0, 3), (3, 3), (6, 2), (8, 2)]
+
+
+# ---------------------------------------------------------------- dataset wire format / load_data
+def test_dataset_wire_format_round_trip(tmp_path):
+    from nerf_for_angiography_amd.phantomdata import dataset as ds
+    from nerf_for_angiography_amd.nerf.nerf_helpers import sample_pixel_rays
+    angles = ds.angle_grid(90.0, 1, (90, 0))
+    assert len(angles) == 5
+    proj_df, ray_df = ds.make_synthetic_dataset(angles[:2] + angles[-1:], img_size=12, depth_samples_per_ray=40)
+    assert list(proj_df.columns) == ds.PROJ_COLUMNS and list(ray_df.columns) == ds.RAY_COLUMNS
+    assert len(ray_df) == 3 * 144 and 0.0 <= ray_df["pixel_value"].min() and ray_df["pixel_value"].max() <= 1.0
+    folder = str(tmp_path / "ct")
+    name = "background-90.0-1.0-[90, 0]"
+    p, r = ds.save_dataset(proj_df, ray_df, folder, name, binary=False)
+    assert open(p).readline().count(";") == len(ds.PROJ_COLUMNS)      # ';'-separated, index column first
+    proj2, ray2, store, unseen = ds.load_data("ct", name, False, False, 12, 90.0, data_root=str(tmp_path))
+    assert store == folder and unseen is None
+    np.testing.assert_allclose(ray2.to_numpy(), ray_df.to_numpy(), rtol=1e-12)
+    assert proj2["tform_cam2world"].iloc[1] == proj_df["tform_cam2world"].iloc[1]
+    np.testing.assert_allclose(np.array(proj2["image_data"].iloc[0]), np.array(proj_df["image_data"].iloc[0]), rtol=1e-12)
+    with pytest.raises(FileNotFoundError):
+        ds.load_data("ct", "nope", False, False, 12, 90.0, data_root=str(tmp_path))
+    # the frames feed the reference's weighted pixel sampler unchanged
+    ray2["ray_origins"] = ray2[["ray_origins_x", "ray_origins_y", "ray_origins_z"]].to_numpy().tolist()
+    ray2["ray_directions"] = ray2[["ray_directions_x", "ray_directions_y", "ray_directions_z"]].to_numpy().tolist()
+    o, d, pix = sample_pixel_rays(ray2, 50, "cpu", weights="distance_pixel_value")
+    assert o.shape == (50, 3) and d.shape == (50, 3) and pix.shape == (50,) and pix.dtype == torch.float32
+    w = ds.sampling_weights(np.array(proj_df["image_data"].iloc[0]), "segmentation")
+    assert w.shape == (12, 12) and w.min() > 0
+    with pytest.raises(NotImplementedError):
+        ds.sampling_weights(w, "frangi")
+
+
+def test_training_driver_flags_match_reference():
+    from nerf_for_angiography_amd.nerf.run_nerf_acc import build_parser
+    ns = build_parser().parse_args(["--limited_size", "90", "--number_angles", "2", "--center_point", "[90,0]", "--binary", "True",
+                                    "--sampling_strategy", "random", "--data_name", "ct", "--num_layers", "8",
+                                    "--num_hidden_units", "256"])
+    assert (ns.limited_size, ns.num_layers, ns.binary) == ("90", "8", "True")     # strings, cast later as upstream
