@@ -155,10 +155,17 @@ def main():
                 "wgrad_hbm_read_GBps_algorithmic": round(stash_bytes * samples_per_step / max(prof["wgrad"][0] / args.steps * 1e-3, 1e-9) / 1e9, 1),
                 "step_tflops_algorithmic": round((fwd_f + dgrad_f + wgrad_f) * value / world / 1e12, 2),
                 "step_frac_of_peak": round((fwd_f + dgrad_f + wgrad_f) * value / world / 1e12 / peak, 4)}
+    # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/r01_bf16_pmc.md);
+    # only valid for the configuration those passes ran (the default one)
     traffic_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(traffic_file):      # HBM bytes per launch from the committed rocprofv3 --pmc passes
+    default_cfg = (W, S, args.layers, args.width, fused, abs(args.workspace_gib - 24.0) < 1e-9) == (512, 128, 8, 256, True, True)
+    if default_cfg and os.path.exists(traffic_file):
         try:
-            roofline["traffic"] = json.load(open(traffic_file)).get(args.precision)
+            t = json.load(open(traffic_file)).get(args.precision)
+            if t:
+                roofline["traffic"] = float(t["bytes_per_launch"])
+                roofline["traffic_source"] = t["source"]
+                roofline["algorithmic_bytes_per_launch"] = float((stash_bytes + 72) * per_launch_samples)
         except Exception:
             pass
 

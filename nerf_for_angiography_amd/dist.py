@@ -20,6 +20,10 @@ def init_from_env(backend: str | None = None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_cuda = torch.cuda.is_available()
+    # rehearsal knobs (several ranks on one GPU over gloo): AFX_DEVICE_INDEX pins the device, AFX_DIST_BACKEND the backend
+    if os.environ.get("AFX_DEVICE_INDEX") is not None:
+        local = int(os.environ["AFX_DEVICE_INDEX"])
+    backend = backend or os.environ.get("AFX_DIST_BACKEND")
     if use_cuda:
         torch.cuda.set_device(local)
     if world > 1 and not dist.is_initialized():
