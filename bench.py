@@ -59,7 +59,7 @@ def main():
     from nerf_for_angiography_amd.model.CPPN import CPPN
     from nerf_for_angiography_amd.render import render_projection, render_rays, train_step_mse, projection_spec
     from nerf_for_angiography_amd.phantomdata.proj_helpers import source_matrix
-    from nerf_for_angiography_amd.phantomdata.helpers import capsule_tree, capsule_mu, ray_tracing, get_ray_values
+    from nerf_for_angiography_amd.phantomdata.helpers import capsule_tree, capsule_mu, ray_tracing_fn as ray_tracing, get_ray_values
 
     rank, world, device = afx_dist.init_from_env()
     if not torch.cuda.is_available():

@@ -184,6 +184,14 @@ int afx_composite_packed_backward(const float* pred, const int32_t* ray_indices,
 int afx_fine_depths(const float* z_coarse, int z_per_ray, const float* w_coarse, const float* u,
                     int64_t n_rays, int32_t n_coarse, int32_t n_fine, float* z_out, void* stream);
 
+/* Ground-truth projector ray_tracing(interpolator, ...) — phantomdata/helpers.py:192-224 — for a voxel volume
+ * vol[nx,ny,nz] (C order) on the regular grid axis_k = origin_k + i*spacing_k, trilinear interpolation with
+ * `fill_value` outside (scipy RegularGridInterpolator(method='linear', bounds_error=False, fill_value) as built by
+ * get_interpolator_from_* :72-154).  Rays and depths come from `args` (ray_mode, z[S] shared, pixel out [R]).
+ * type_ct != 0: img = prod exp(-mu*dz*||d||), last dz = 1e10;  type_ct == 0: img = prod exp(-mu). */
+int afx_project_volume(const float* vol, int32_t nx, int32_t ny, int32_t nz, const double origin[3], const double spacing[3],
+                       float fill_value, const afx_render_args* args, int type_ct, void* stream);
+
 /* Measurement aid (bench.py's roofline leg): when enabled, every launch of the three MFMA kernels is
  * bracketed by HIP events recorded on the launch stream.  afx_profile_read blocks on those events
  * (the only call in this library that synchronises), returns the summed device time and the launch

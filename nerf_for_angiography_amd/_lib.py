@@ -55,6 +55,8 @@ _SIGS = {
                                        C.c_void_p]),
     "afx_composite_packed_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "afx_project_volume": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                     C.c_float, C.POINTER(RenderArgs), C.c_int, C.c_void_p]),
     "afx_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "afx_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "afx_fine_depths": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,

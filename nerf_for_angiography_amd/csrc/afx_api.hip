@@ -532,6 +532,29 @@ extern "C" int afx_mlp_backward(afx_ctx* c, int prec, const void* prepared, cons
   return run_backward(c, prec, a, 0, (char*)workspace, workspace_bytes, grad_flat, (hipStream_t)stream);
 }
 
+extern "C" int afx_project_volume(const float* vol, int32_t nx, int32_t ny, int32_t nz, const double origin[3], const double spacing[3],
+                                  float fill_value, const afx_render_args* r, int type_ct, void* stream) {
+  if (!vol || !origin || !spacing || !r) return fail(AFX_E_INVALID, "afx_project_volume: null argument");
+  if (nx < 2 || ny < 2 || nz < 2) return fail(AFX_E_INVALID, "afx_project_volume: volume needs >= 2 voxels per axis");
+  if (!(spacing[0] > 0 && spacing[1] > 0 && spacing[2] > 0)) return fail(AFX_E_INVALID, "afx_project_volume: spacing must be > 0");
+  if (r->n_rays == 0) return AFX_OK;
+  if (r->n_rays < 0 || r->n_samples < 1 || !r->z || !r->pixel || r->depth_mode != AFX_DEPTH_SHARED_Z)
+    return fail(AFX_E_INVALID, "afx_project_volume: needs n_samples >= 1, shared z[S] (AFX_DEPTH_SHARED_Z) and pixel");
+  if (r->ray_mode == AFX_RAYS_ARRAYS) { if (!r->origins || !r->dirs) return fail(AFX_E_INVALID, "afx_project_volume: origins/dirs required"); }
+  else if (r->ray_mode == AFX_RAYS_POSE) { if (!r->poses || r->width <= 0 || r->height <= 0 || !(r->focal > 0)) return fail(AFX_E_INVALID, "afx_project_volume: poses/width/height/focal required"); }
+  else return fail(AFX_E_INVALID, "afx_project_volume: bad ray_mode");
+  ChainArgs a = {};
+  a.org = r->origins; a.dir = r->dirs; a.poses = r->ray_mode == AFX_RAYS_POSE ? r->poses : nullptr;
+  a.ray_ids = r->ray_ids; a.ray_id0 = r->ray_id0; a.width = r->width; a.height = r->height; a.focal = r->focal;
+  a.n_samples = r->n_samples; a.z = r->z; a.n_total = r->n_rays; a.pixel = r->pixel;
+  VolArgs v;
+  v.vol = vol; v.nx = nx; v.ny = ny; v.nz = nz; v.x0 = origin[0]; v.y0 = origin[1]; v.z0 = origin[2];
+  v.dx = spacing[0]; v.dy = spacing[1]; v.dz = spacing[2]; v.fill = fill_value; v.type_ct = type_ct;
+  hipLaunchKernelGGL(k_project_volume, dim3((unsigned)((r->n_rays + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, v);
+  HIPCHK(hipGetLastError());
+  return AFX_OK;
+}
+
 extern "C" int afx_composite_dense(const float* raw, const float* dirs, const float* z, int z_per_ray, int64_t n_rays,
                                    int32_t n_samples, float* rgb_map, float* depth_map, float* weights, float* entropy,
                                    float* sigma, void* stream) {

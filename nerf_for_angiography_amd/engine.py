@@ -288,6 +288,44 @@ def composite_packed_backward(pred, ray_indices, t_starts, t_ends, n_rays, rgb, 
     return d_pred
 
 
+def project_volume(vol, origin, spacing, fill_value, depth_values, origins=None, dirs=None, poses=None, width=0, height=0,
+                   focal=0.0, ray_ids=None, ray_id0=0, n_rays=None, type_ct=True):
+    """afx_project_volume: X-ray projection of a voxel volume (trilinear lookup) along rays -> pixel[R]."""
+    lib = _lib.load()
+    dev = vol.device
+    if not vol.is_cuda:
+        raise AfxError("project_volume: the volume must live on a GPU; there is no CPU fallback")
+    vol = _f32(vol, "volume", dev)
+    if vol.dim() != 3:
+        raise ValueError("volume: expected [nx,ny,nz]")
+    z = _f32(depth_values, "depth_values", dev)
+    a = RenderArgs()
+    keep = [vol, z]
+    if poses is not None:
+        poses = poses[:, :3, :].to(dev, torch.float64).contiguous().reshape(-1, 12)
+        keep.append(poses)
+        n = n_rays if n_rays is not None else (ray_ids.numel() if ray_ids is not None else poses.shape[0] * width * height - ray_id0)
+        a.ray_mode, a.poses = _lib.RAYS_POSE, poses.data_ptr()
+        if ray_ids is not None:
+            ray_ids = ray_ids.to(dev, torch.int32).contiguous()
+            keep.append(ray_ids)
+            a.ray_ids = ray_ids.data_ptr()
+        a.ray_id0, a.width, a.height, a.focal = int(ray_id0), int(width), int(height), float(focal)
+    else:
+        o, d = _f32(origins, "origins", dev), _f32(dirs, "dirs", dev)
+        keep += [o, d]
+        n = o.shape[0]
+        a.ray_mode, a.origins, a.dirs = _lib.RAYS_ARRAYS, o.data_ptr(), d.data_ptr()
+    pixel = torch.empty(int(n), dtype=torch.float32, device=dev)
+    a.n_rays, a.n_samples, a.depth_mode, a.z, a.pixel = int(n), int(z.numel()), _lib.DEPTH_SHARED_Z, z.data_ptr(), pixel.data_ptr()
+    org = (C.c_double * 3)(*[float(x) for x in origin])
+    spc = (C.c_double * 3)(*[float(x) for x in spacing])
+    _lib.check(lib.afx_project_volume(_ptr(vol), vol.shape[0], vol.shape[1], vol.shape[2], org, spc, float(fill_value),
+                                      C.byref(a), int(bool(type_ct)), Engine._stream(dev)), "afx_project_volume")
+    del keep
+    return pixel
+
+
 def fine_depths(z_coarse, w_coarse, u):
     lib = _lib.load()
     dev = w_coarse.device

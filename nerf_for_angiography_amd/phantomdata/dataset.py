@@ -21,7 +21,7 @@ import pandas as pd
 import torch
 from scipy.ndimage import distance_transform_edt
 
-from .helpers import capsule_mu, capsule_tree, get_depth_values, get_ray_values, ray_tracing
+from .helpers import capsule_mu, capsule_tree, get_depth_values, get_ray_values, ray_tracing_fn as ray_tracing
 
 PROJ_COLUMNS = ["image_id", "theta", "phi", "larm", "theta_shift", "phi_shift", "larm_shift", "translation_x",
                 "translation_y", "translation_z", "tform_cam2world", "unshifted_tform_cam2world", "image_data",

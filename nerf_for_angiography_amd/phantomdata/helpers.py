@@ -61,8 +61,42 @@ def capsule_mu(points, capsules, mu=0.2):
     return inside.to(points.dtype) * mu
 
 
-def ray_tracing(mu_fn, ray_origins, ray_directions, depth_values, batch_rays=8192):
-    """Ground-truth X-ray projection (helpers.py:192-224, 'ct' branch) for a callable attenuation field:
+class VoxelVolume:
+    """A voxel phantom on a regular grid — what get_interpolator_from_vol_* / _from_grid (helpers.py:72-154) wrap in a
+    scipy RegularGridInterpolator(method='linear', bounds_error=False, fill_value=min(scalars)).  `values` [nx,ny,nz]
+    lives on the GPU; projection through it runs in the HIP kernel behind afx_project_volume."""
+
+    def __init__(self, points_x, points_y, points_z, values, fill_value=None, device="cuda:0"):
+        self.axes = [np.asarray(a, dtype=np.float64) for a in (points_x, points_y, points_z)]
+        for a in self.axes:
+            if len(a) < 2 or not np.allclose(np.diff(a), a[1] - a[0], rtol=1e-9, atol=1e-12):
+                raise ValueError("VoxelVolume: the grid must be regular (uniform spacing) along every axis")
+        v = np.asarray(values, dtype=np.float32)
+        if v.shape != tuple(len(a) for a in self.axes):
+            raise ValueError("VoxelVolume: values shape does not match the axes")
+        self.fill_value = float(np.min(v)) if fill_value is None else float(fill_value)
+        self.values = torch.from_numpy(np.ascontiguousarray(v)).to(device)
+        self.origin = [float(a[0]) for a in self.axes]
+        self.spacing = [float(a[1] - a[0]) for a in self.axes]
+
+
+def ray_tracing(interpolator, angles, ray_origins, ray_directions, depth_values, img_width, img_height, ii, jj, batch_size,
+                device, proj_folder_name=None, type='ct', invert=False):
+    """Upstream signature (helpers.py:192).  `interpolator`: a VoxelVolume (fused HIP projector; the tiling by
+    `batch_size` and the per-row PNG dumps of the reference are unnecessary) or a callable mu(points)."""
+    if isinstance(interpolator, VoxelVolume):
+        from ..engine import project_volume
+        dev = interpolator.values.device
+        o = ray_origins.reshape(-1, 3).to(dev, torch.float32).contiguous()
+        d = ray_directions.reshape(-1, 3).to(dev, torch.float32).contiguous()
+        img = project_volume(interpolator.values, interpolator.origin, interpolator.spacing, interpolator.fill_value,
+                             depth_values.to(dev, torch.float32), origins=o, dirs=d, type_ct=(type == 'ct'))
+        return img.reshape(int(np.ceil(img_height)), int(np.ceil(img_width)))
+    return ray_tracing_fn(interpolator, ray_origins, ray_directions, depth_values).reshape(int(img_height), int(img_width))
+
+
+def ray_tracing_fn(mu_fn, ray_origins, ray_directions, depth_values, batch_rays=8192):
+    """Ground-truth X-ray projection ('ct' branch) for a callable attenuation field mu(points):
     img = prod_s exp(-mu(o + d z_s) * dz_s * ||d||), dz_last = 1e10 (harmless: mu(far plane) = 0)."""
     shape = ray_origins.shape[:-1]
     o, d = ray_origins.reshape(-1, 3), ray_directions.reshape(-1, 3)

@@ -449,3 +449,27 @@ def capsule_mu(p: Tensor, caps: np.ndarray, mu: float = 0.2) -> Tensor:
         dist = torch.norm(p - (a[i] + t[:, None] * ab[i]), dim=-1)
         inside |= dist <= r[i]
     return inside.to(p.dtype) * mu
+
+
+# --------------------------------------------------------------------------
+# R14 over a voxel volume.  phantomdata/helpers.py:72-154 (interpolator) + :192-224 (ray_tracing).
+# Literal: scipy RegularGridInterpolator(method='linear', bounds_error=False, fill_value=min), float64 points,
+# weights = exp(-mu * dists * ||d||) ('ct') or exp(-mu), product over samples.  (scipy is the reference's own
+# dependency and is present, so this IS the reference algorithm, not a restatement of it.)
+# --------------------------------------------------------------------------
+
+def project_volume_scipy(axes, values, o: Tensor, d: Tensor, z: Tensor, type_ct: bool = True, fill_value=None):
+    from scipy.interpolate import RegularGridInterpolator
+    fv = float(np.min(values)) if fill_value is None else fill_value
+    interp = RegularGridInterpolator(tuple(np.asarray(a, dtype=np.float64) for a in axes), np.asarray(values, dtype=np.float64),
+                                     method="linear", bounds_error=False, fill_value=fv)
+    o64, d64 = o.double(), d.double()
+    pts = o64[..., None, :] + d64[..., None, :] * z[..., :, None]
+    big = torch.tensor([1e10], dtype=z.dtype)
+    dists = torch.cat((z[1:] - z[:-1], big), -1)
+    mu = torch.from_numpy(interp(pts.numpy().reshape(-1, 3))).reshape(pts.shape[:-1])
+    if type_ct:
+        w = torch.exp(-mu * (dists * torch.norm(d64[..., None, :], dim=-1)))
+    else:
+        w = torch.exp(-mu)
+    return w.prod(-1).float()
