@@ -449,6 +449,7 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
   a.stash_e = (float*)(ws + off); off += rows * k0ld * 4;
   a.graw = (float*)(ws + off);
   a.stash_rows = (int64_t)rows;
+  a.debug = 16;      // stash stores non-temporal (bits 4-5: 0 plain, 1 nt, 2 sc1); AFX_DEBUG overrides for timing experiments
   if (const char* e = getenv("AFX_DEBUG")) a.debug = atoi(e);
   for (int64_t t0 = 0; t0 < tiles; t0 += chunk) {
     const int64_t t1 = t0 + chunk < tiles ? t0 + chunk : tiles;
@@ -469,7 +470,7 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
     int64_t rps = (w.rows + splits - 1) / splits;
     rps = (rps + 63) / 64 * 64;        // whole 32-/64-sample stages
     w.rows_per_split = (int)rps;
-    w.partial = partial; w.partial2 = partial2; w.partial_s = partial_s;
+    w.partial = partial; w.partial2 = partial2; w.partial_s = partial_s; w.debug = a.debug;
     ReduceArgs rd;
     rd.partial = partial; rd.partial2 = partial2; rd.n_hidden = N; rd.k0 = c->k0; rd.k0pad = k0ld; rd.n_splits = splits;
     rd.grad = grad_flat; rd.hidden_only = b16 ? 1 : 0; rd.partial_s = partial_s;

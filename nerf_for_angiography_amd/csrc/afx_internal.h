@@ -66,6 +66,7 @@ struct WgradArgs {
   int32_t n_splits, rows_per_split;   // rows_per_split even
   float* partial;           // [(N+1), n_splits, F*F]
   float* partial2;          // [(N+2), n_splits, F+4]
+  int32_t debug;            // timing experiments only (bit5: default-policy instead of non-temporal stash loads)
   float* partial_s;         // bf16 path: [n_small, F*k0pad + 2F + 4] first-layer / output-layer partials
 };
 

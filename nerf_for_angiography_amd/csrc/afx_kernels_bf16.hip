@@ -52,6 +52,17 @@ template <int F> __device__ __forceinline__ uint32_t stash_off(uint32_t r, int c
   return ((((r >> 5) * (F / 8) + ch) << 5) + (r & 31)) << 4;      // < 2^32: the host bounds a layer's stash
 }
 
+// 16-byte stash store; `mode` (uniform): 0 plain, 1 non-temporal (default), 2 sc1 (write-through).
+// The stash is written once and read once by another kernel; non-temporal stores keep it from displacing the weight
+// slabs that every workgroup re-streams from L2.  A/B in one process on the 512^2x128 step, k_chain<bwd>:
+// plain 116 ms, nt 99 ms, sc1 121 ms.  (Keep the three arms: a two-arm version of this function compiled to a
+// slower store placement and lost the gain.)
+__device__ __forceinline__ void stash_store(char* p, u32x4 v, int mode) {
+  if (mode == 1) __builtin_nontemporal_store(v, (u32x4*)p);
+  else if (mode == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+  else *(u32x4*)p = v;
+}
+
 template <int F, bool X3, bool ENC, bool BWD, int NW>
 __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs a) {
   static_assert(!(X3 && BWD), "the backward chain runs in plain bf16");
@@ -100,7 +111,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
   constexpr int SPS = 2 * NCG;
   bool first_step = true;
   auto step_begin = [&]() -> const u32x4* {
-    if (BWD && !first_step && !a.debug) {
+    if (BWD && !first_step && !(a.debug & 15)) {
       if (SPS == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
     } else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
@@ -190,7 +201,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
           // stash position of feature 32t+16s+8(j>>2)+4h+(j&3) is p = 32t+16s+8h+j (bits 2,3 swapped; the
           // weight-gradient kernels undo it with fperm).  Layout [row>>5][p>>3][row&31][8 bf16]: the 64 lanes
           // of this store write one contiguous 1 KiB run (32 samples x 16 B for h = 0, then for h = 1).
-          *(u32x4*)((char*)a.stash_h + (size_t)l * a.stash_rows * (F * 2) + (so[cg] + (uint32_t)(4 * t + 2 * s) * 512u)) = nf[s];
+          stash_store((char*)a.stash_h + (size_t)l * a.stash_rows * (F * 2) + (so[cg] + (uint32_t)(4 * t + 2 * s) * 512u), nf[s], (a.debug >> 4) & 3);
         }
       }
     };
@@ -205,13 +216,20 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
     // slab in groups of G k-steps, two groups in flight (explicit software pipeline; sched_barrier keeps
     // hipcc from sinking the reads back next to their MFMAs), so LDS latency hides behind >= G MFMAs.
     auto mma_step = [&](const u32x4* sl, u32x4 (*bh)[NT][2], u32x4 (*bl)[X3 ? NT : 1][2], f32x16* acc) {
-      if (BWD) {      // the backward kernel is register-bound: no explicit read pipeline
+      if (BWD) {      // the backward kernel is register-bound: a rolling PF-deep prefetch (PF*4 VGPRs) only
+        constexpr int PF = 3;
+        u32x4 ar[PF];
+#pragma unroll
+        for (int i = 0; i < PF; ++i) ar[i] = sl[i * 64 + lane];
 #pragma unroll
         for (int u = 0; u < 2 * NT; ++u) {
-          const u32x4 ah = sl[u * 64 + lane];
+          const u32x4 ah = ar[u % PF];
+          if (u + PF < 2 * NT) ar[u % PF] = sl[(u + PF) * 64 + lane];
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int cg = 0; cg < NCG; ++cg) acc[cg] = mfma_bf16(ah, bh[cg][u >> 1][u & 1], acc[cg]);
         }
+        __builtin_amdgcn_sched_barrier(0);
         return;
       }
       constexpr int G = (X3 || NW == 8) ? 2 : 4;
@@ -407,12 +425,19 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
         }
       }
       auto mma_step_plain = [&](const u32x4* sl, u32x4 (*bh)[NT][2], f32x16* acc) {
+        constexpr int PF = 3;
+        u32x4 ar[PF];
+#pragma unroll
+        for (int i = 0; i < PF; ++i) ar[i] = sl[i * 64 + lane];
 #pragma unroll
         for (int u = 0; u < 2 * NT; ++u) {
-          const u32x4 ah = sl[u * 64 + lane];
+          const u32x4 ah = ar[u % PF];
+          if (u + PF < 2 * NT) ar[u % PF] = sl[(u + PF) * 64 + lane];
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int cg = 0; cg < NCG; ++cg) acc[cg] = mfma_bf16(ah, bh[cg][u >> 1][u & 1], acc[cg]);
         }
+        __builtin_amdgcn_sched_barrier(0);
       };
       auto stash_dz_tile = [&](int l, int t) {
         if (a.debug & 1) return;
@@ -420,7 +445,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
         for (int cg = 0; cg < NCG; ++cg)
 #pragma unroll
           for (int s = 0; s < 2; ++s)
-            *(u32x4*)((char*)a.stash_dz + (size_t)l * a.stash_rows * (F * 2) + (so[cg] + (uint32_t)(4 * t + 2 * s) * 512u)) = dz[cg][t][s];
+            stash_store((char*)a.stash_dz + (size_t)l * a.stash_rows * (F * 2) + (so[cg] + (uint32_t)(4 * t + 2 * s) * 512u), dz[cg][t][s], (a.debug >> 4) & 3);
       };
       for (int l = N; l >= 1; --l) {
         u32x4 dn[NCG][NT][2];
@@ -504,6 +529,7 @@ __global__ void __launch_bounds__(512) k_wgrad_bf16(const WgradArgs a) {
     const int64_t g0 = (r0 + (int64_t)st * KB) >> 5;
     for (int c = wave; c < NCH; c += 8) {
       const size_t src = ((((size_t)(g0 + hh) * NCH + c) << 5) + col) << 4;
+      // default cache policy: non-temporal loads (aux = 2) measured 2 ms slower per step here
       __builtin_amdgcn_global_load_lds(GPTR(A + src), LPTR(dA + c * CS), 16, 0, 0);
       __builtin_amdgcn_global_load_lds(GPTR(B + src), LPTR(dB + c * CS), 16, 0, 0);
     }
