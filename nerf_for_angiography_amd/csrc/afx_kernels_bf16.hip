@@ -170,15 +170,21 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
 
     // epilogue of one output tile: ReLU, (mask), next fragments, (stash), output-layer dot product
     auto epilogue = [&](int l, int t, const f32x16& acc, int cg, u32x4* nf, u32x4* nl, uint32_t* mw) {
+      // ReLU and its mask with integer VALU ops only (no compare -> SGPR lane masks, which hipcc spills here):
+      // for a non-NaN float x, max_i32(bits(x), 0) is bits(relu(x)), and min_u32(that, 1) is [x > 0].
       float v[16];
       uint32_t bits = 0;
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        const bool pos = acc[j] > 0.f;
-        v[j] = pos ? acc[j] : 0.f;
-        bits |= (pos ? 1u : 0u) << j;
+        const int ri = max(__float_as_int(acc[j]), 0);
+        v[j] = __int_as_float(ri);
+        if (BWD) bits |= min((uint32_t)ri, 1u) << j;
       }
-      if (BWD) mw[(t >> 1) * NCG + cg] |= bits << (16 * (t & 1));
+      if (BWD) {
+        uint32_t& word = mw[cg];                     // one live word per column group: tiles 2k (low half), 2k+1 (high half)
+        word = (t & 1) ? (word | (bits << 16)) : bits;
+        if ((t & 1) || t == NT - 1) mk[((l * MW + (t >> 1)) * NCG + cg) * NTH + tid] = word;
+      }
       if (l == N) {
         const f32x4* wp = (const f32x4*)(wout_perm + (hh * NT + t) * 16);
 #pragma unroll
@@ -217,7 +223,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
     // hipcc from sinking the reads back next to their MFMAs), so LDS latency hides behind >= G MFMAs.
     auto mma_step = [&](const u32x4* sl, u32x4 (*bh)[NT][2], u32x4 (*bl)[X3 ? NT : 1][2], f32x16* acc) {
       if (BWD) {      // the backward kernel is register-bound: a rolling PF-deep prefetch (PF*4 VGPRs) only
-        constexpr int PF = 3;
+        constexpr int PF = 2;
         u32x4 ar[PF];
 #pragma unroll
         for (int i = 0; i < PF; ++i) ar[i] = sl[i * 64 + lane];
@@ -288,10 +294,6 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
 #pragma unroll
         for (int cg = 0; cg < NCG; ++cg) epilogue(0, t, acc[cg], cg, hf[cg][t], hl[X3 ? cg : 0][X3 ? t : 0], mw);
       }
-      if (BWD) {
-#pragma unroll
-        for (int w = 0; w < MW * NCG; ++w) mk[(0 * MW * NCG + w) * NTH + tid] = mw[w];
-      }
     }
     // ---------------- hidden layers
     for (int l = 1; l <= N; ++l) {
@@ -329,10 +331,6 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
 #pragma unroll
         for (int cg = 0; cg < NCG; ++cg)
           epilogue(l, NT - 1, accp[cg], cg, nf[cg][NT - 1], nl[X3 ? cg : 0][X3 ? NT - 1 : 0], mw);
-      }
-      if (BWD) {
-#pragma unroll
-        for (int w = 0; w < MW * NCG; ++w) mk[(l * MW * NCG + w) * NTH + tid] = mw[w];
       }
 #pragma unroll
       for (int cg = 0; cg < NCG; ++cg)
@@ -416,7 +414,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
           for (int q = 0; q < 4; ++q) {
             const f32x4 w4 = wp[q];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[4 * q + e] = ((bits >> (4 * q + e)) & 1u) ? w4[e] * g[cg] : 0.f;
+            for (int e = 0; e < 4; ++e)
+              v[4 * q + e] = __int_as_float(__float_as_int(w4[e] * g[cg]) & (((int)(bits << (31 - (4 * q + e)))) >> 31));
           }
 #pragma unroll
           for (int s = 0; s < 2; ++s)
@@ -462,7 +461,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
             const uint32_t bits = mk[(((l - 1) * MW + (t >> 1)) * NCG + cg) * NTH + tid] >> (16 * (t & 1));
             float v[16];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = ((bits >> j) & 1u) ? acc[cg][j] : 0.f;
+            for (int j = 0; j < 16; ++j)      // sign-extended 1-bit field (v_bfe_i32) as an AND mask
+              v[j] = __int_as_float(__float_as_int(acc[cg][j]) & (((int)(bits << (31 - j))) >> 31));
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
