@@ -52,16 +52,10 @@ template <int F> __device__ __forceinline__ uint32_t stash_off(uint32_t r, int c
   return ((((r >> 5) * (F / 8) + ch) << 5) + (r & 31)) << 4;      // < 2^32: the host bounds a layer's stash
 }
 
-// 16-byte stash store; `mode` (uniform): 0 plain, 1 non-temporal (default), 2 sc1 (write-through).
-// The stash is written once and read once by another kernel; non-temporal stores keep it from displacing the weight
-// slabs that every workgroup re-streams from L2.  A/B in one process on the 512^2x128 step, k_chain<bwd>:
-// plain 116 ms, nt 99 ms, sc1 121 ms.  (Keep the three arms: a two-arm version of this function compiled to a
-// slower store placement and lost the gain.)
-__device__ __forceinline__ void stash_store(char* p, u32x4 v, int mode) {
-  if (mode == 1) __builtin_nontemporal_store(v, (u32x4*)p);
-  else if (mode == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
-  else *(u32x4*)p = v;
-}
+// 16-byte stash store, non-temporal: the stash is written once and read once by another kernel, so it must not
+// displace the weight slabs every workgroup re-streams from L2.  A/B in one process on the 512^2x128 step,
+// k_chain<bwd>: plain 116 ms, nt 99 ms, sc1 (write-through) 121 ms.
+__device__ __forceinline__ void stash_store(char* p, u32x4 v, int) { __builtin_nontemporal_store(v, (u32x4*)p); }
 
 template <int F, bool X3, bool ENC, bool BWD, int NW>
 __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs a) {
@@ -81,7 +75,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
   float* sm = (float*)lds;
   for (uint32_t i = tid * 4; i < a.small_floats; i += NTH * 4) *(f32x4*)(sm + i) = *(const f32x4*)(a.small + i);
   char* slot0 = lds + a.small_bytes_pad;
-  uint32_t* mk = (uint32_t*)(slot0 + 2 * (size_t)a.slot_bytes);   // [((l*MW + w)*NCG + cg)*NTH + tid]
+  uint32_t* mk = (uint32_t*)(slot0 + 2 * (size_t)a.slot_bytes);   // ReLU masks, 16 bits per (layer, tile, column group, thread)
+  unsigned short* mk16 = (unsigned short*)mk;                     // [((l*NT + t)*NCG + cg)*NTH + tid]
   const float* bias_perm = sm;
   const float* wout_perm = sm + (N + 1) * F;
   const float* aux = sm + (N + 2) * F + 4;
@@ -180,11 +175,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
         v[j] = __int_as_float(ri);
         if (BWD) bits |= min((uint32_t)ri, 1u) << j;
       }
-      if (BWD) {
-        uint32_t& word = mw[cg];                     // one live word per column group: tiles 2k (low half), 2k+1 (high half)
-        word = (t & 1) ? (word | (bits << 16)) : bits;
-        if ((t & 1) || t == NT - 1) mk[((l * MW + (t >> 1)) * NCG + cg) * NTH + tid] = word;
-      }
+      if (BWD) mk16[((l * NT + t) * NCG + cg) * NTH + tid] = (unsigned short)bits;   // 16 ReLU bits per tile, written at once
       if (l == N) {
         const f32x4* wp = (const f32x4*)(wout_perm + (hh * NT + t) * 16);
 #pragma unroll
@@ -407,7 +398,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
         if (hh == 0) a.graw[m[cg]] = g[cg];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          const uint32_t bits = mk[((N * MW + (t >> 1)) * NCG + cg) * NTH + tid] >> (16 * (t & 1));
+          const uint32_t bits = mk16[((N * NT + t) * NCG + cg) * NTH + tid];
           const f32x4* wp = (const f32x4*)(wout_perm + (hh * NT + t) * 16);
           float v[16];
 #pragma unroll
@@ -458,7 +449,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
           mma_step_plain(sl, dz, acc);
 #pragma unroll
           for (int cg = 0; cg < NCG; ++cg) {
-            const uint32_t bits = mk[(((l - 1) * MW + (t >> 1)) * NCG + cg) * NTH + tid] >> (16 * (t & 1));
+            const uint32_t bits = mk16[(((l - 1) * NT + t) * NCG + cg) * NTH + tid];
             float v[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j)      // sign-extended 1-bit field (v_bfe_i32) as an AND mask
