@@ -38,6 +38,9 @@ struct afx_ctx {
   int n_cu;
   std::set<const void*> attr_done;
   bool profiling;
+  hipStream_t side = nullptr;          // overlap mode: weight-gradient kernels run here (fork/join with events)
+  hipEvent_t ev_chain[2] = {nullptr, nullptr}, ev_wgrad[2] = {nullptr, nullptr};
+  int overlap, persistent_chain;
   int nw_plain;          // waves per workgroup of the plain-bf16 chain kernels (8, or 4 via AFX_NW=4)
   std::vector<ProfRec> recs;
 };
@@ -124,6 +127,9 @@ extern "C" int afx_create(const afx_model_desc* d, afx_ctx** out) {
     c->n_cu = prop.multiProcessorCount;
   c->profiling = false;
   c->nw_plain = 8;
+  c->overlap = 0; c->persistent_chain = 0;     // AFX_OVERLAP=1: chain(i+1) || wgrad(i) on two streams (+2.6 % on the 512^2x128 step; per-kernel times inflate)
+  if (const char* e = getenv("AFX_OVERLAP")) c->overlap = atoi(e);
+  if (const char* e = getenv("AFX_PERSISTENT")) c->persistent_chain = atoi(e);
   if (const char* e = getenv("AFX_NW")) { if (atoi(e) == 4) c->nw_plain = 4; }
   *out = c;
   return AFX_OK;
@@ -132,6 +138,9 @@ extern "C" int afx_create(const afx_model_desc* d, afx_ctx** out) {
 extern "C" void afx_destroy(afx_ctx* c) {
   if (!c) return;
   for (auto& r : c->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  for (auto e : c->ev_chain) if (e) (void)hipEventDestroy(e);
+  for (auto e : c->ev_wgrad) if (e) (void)hipEventDestroy(e);
+  if (c->side) (void)hipStreamDestroy(c->side);
   delete c;
 }
 
@@ -206,13 +215,13 @@ extern "C" int64_t afx_query(const afx_ctx* c, int what, int64_t a0, int64_t a1,
     case AFX_Q_FWD_WORKSPACE: return (int64_t)rup64((size_t)a0 * (size_t)(s_pad_of((int)a1) / GROUP) * 4, 256);
     case AFX_Q_BWD_WORKSPACE_MIN: {
       BwdLayout B = bwd_layout(c, (int)a2, a0);
-      return (int64_t)(B.fixed_bytes + 32 * B.per_tile_bytes);
+      return (int64_t)(B.fixed_bytes + 32 * B.per_tile_bytes + 1024);
     }
     case AFX_Q_BWD_WORKSPACE_FULL: {
       BwdLayout B = bwd_layout(c, (int)a2, a0);
       const int64_t samples = a0 > 0 ? a0 * s_pad_of((int)a1) : a1;
       const int64_t tiles = (samples + bwd_tile((int)a2) - 1) / bwd_tile((int)a2);
-      return (int64_t)(B.fixed_bytes + (size_t)tiles * B.per_tile_bytes);
+      return (int64_t)(B.fixed_bytes + (size_t)tiles * B.per_tile_bytes + 1024);
     }
   }
   fail(AFX_E_INVALID, "afx_query: unknown query %d", what);
@@ -295,7 +304,7 @@ static int launch_chain(afx_ctx* c, int prec, bool bwd, const ChainArgs& a, hipS
   if (lds > 160 * 1024) return fail(AFX_E_INVALID, "model needs %zu B of LDS (> 160 KiB)", lds);
   const int tiles = a.tile1 - a.tile0;
   if (tiles <= 0) return AFX_OK;
-  const int grid = tiles < c->n_cu ? tiles : c->n_cu;
+  const int grid = (tiles < c->n_cu || !a.persistent) ? tiles : c->n_cu;    // persistent: one workgroup per CU loops over tiles
   if (F == 64) return launch_chain_f<64>(c, prec, bwd, a, lds, grid, st);
   if (F == 128) return launch_chain_f<128>(c, prec, bwd, a, lds, grid, st);
   return launch_chain_f<256>(c, prec, bwd, a, lds, grid, st);
@@ -313,6 +322,7 @@ static void fill_model(const afx_ctx* c, int prec, bool bwd, const void* prepare
   a.slabh_bytes = (prec == AFX_PREC_BF16X3 && bwd) ? L.slabt_bytes : L.slabh_stride;
   a.slot_bytes = a.slab0_bytes > a.slabh_bytes ? a.slab0_bytes : a.slabh_bytes;
   a.n_hidden = c->d.n_hidden; a.k0 = c->k0; a.nq = c->nq; a.enc = c->d.enc; a.n_freq = c->d.n_freq;
+  a.persistent = 1;
 }
 
 extern "C" int afx_mlp_infer(afx_ctx* c, int prec, const void* prepared, const float* pts, int64_t n_pts, float* out,
@@ -434,28 +444,55 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
   const bool b16 = is_bf16(prec);
   const size_t esz = b16 ? 2 : 4;                       // stash element size
   const int k0ld = b16 ? 16 * nk0_of(c) : c->k0pad;     // row length of the encoded-input stash
-  if (ws_bytes < fixed + B.per_tile_bytes) return fail(AFX_E_WORKSPACE, "backward workspace %zu too small (min %zu)", ws_bytes, fixed + 32 * B.per_tile_bytes);
+  if (ws_bytes < fixed + B.per_tile_bytes + 1024) return fail(AFX_E_WORKSPACE, "backward workspace %zu too small (min %zu)", ws_bytes, fixed + 32 * B.per_tile_bytes);
   const int64_t tiles = (a.n_total + TILE - 1) / TILE;
-  int64_t chunk = (int64_t)((ws_bytes - fixed) / B.per_tile_bytes);
+  int64_t chunk = (int64_t)((ws_bytes - fixed - 1024) / B.per_tile_bytes);      // 1 KiB slack for buffer alignment
   if (chunk > tiles) chunk = tiles;
+  // Overlap mode: two half-size stash buffers; the weight-gradient kernels of chunk i run on a side stream while
+  // the chain kernel of chunk i+1 runs on the caller's stream (one is MFMA/HBM-write heavy, the other HBM-read
+  // bound).  Fork/join with events only; the side stream always rejoins the caller's stream before returning.
+  int nbuf = 1;
+  if (c->overlap && chunk < tiles && chunk >= 2 * c->n_cu) {
+    if (!c->side) {
+      HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+      for (auto& e : c->ev_chain) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      for (auto& e : c->ev_wgrad) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    nbuf = 2;
+    chunk /= 2;
+  }
   size_t off = head;
   float* partial = (float*)(ws + off); off += rup64((size_t)(N + 1) * kSplits * F * F * 4, 256);
   float* partial2 = (float*)(ws + off); off += rup64((size_t)(N + 2) * kSplits * (F + 4) * 4, 256);
   float* partial_s = (float*)(ws + off);
   if (b16) off += rup64((size_t)kSmallBlocks * (F * k0ld + 2 * F + 4) * 4, 256);
   const size_t rows = (size_t)chunk * TILE;
-  a.stash_h = (float*)(ws + off); off += (size_t)(N + 1) * rows * F * esz;
-  a.stash_dz = (float*)(ws + off); off += (size_t)(N + 1) * rows * F * esz;
-  a.stash_e = (float*)(ws + off); off += rows * k0ld * 4;
-  a.graw = (float*)(ws + off);
+  float *stash_h[2], *stash_dz[2], *stash_e[2], *graw[2];
+  for (int bI = 0; bI < nbuf; ++bI) {
+    stash_h[bI] = (float*)(ws + off); off += (size_t)(N + 1) * rows * F * esz;
+    stash_dz[bI] = (float*)(ws + off); off += (size_t)(N + 1) * rows * F * esz;
+    stash_e[bI] = (float*)(ws + off); off += rows * k0ld * 4;
+    graw[bI] = (float*)(ws + off); off += rup64(rows * 4, 256);
+  }
   a.stash_rows = (int64_t)rows;
-  a.debug = 16;      // stash stores non-temporal (bits 4-5: 0 plain, 1 nt, 2 sc1); AFX_DEBUG overrides for timing experiments
+  a.debug = 16;      // AFX_DEBUG: timing experiments only (bit0 skip stash stores, bits0-3 also force vmcnt(0))
   if (const char* e = getenv("AFX_DEBUG")) a.debug = atoi(e);
-  for (int64_t t0 = 0; t0 < tiles; t0 += chunk) {
+  a.persistent = (nbuf == 2 && !c->persistent_chain) ? 0 : 1;
+  int64_t ci = 0;
+  for (int64_t t0 = 0; t0 < tiles; t0 += chunk, ++ci) {
     const int64_t t1 = t0 + chunk < tiles ? t0 + chunk : tiles;
+    const int bI = nbuf == 2 ? (int)(ci & 1) : 0;
     a.tile0 = (int)t0; a.tile1 = (int)t1;
+    a.stash_h = stash_h[bI]; a.stash_dz = stash_dz[bI]; a.stash_e = stash_e[bI]; a.graw = graw[bI];
+    if (nbuf == 2 && ci >= 2) HIPCHK(hipStreamWaitEvent(st, c->ev_wgrad[bI], 0));     // buffer bI has been consumed
     int rc = launch_chain(c, prec, true, a, st);
     if (rc) return rc;
+    hipStream_t ws_st = st;
+    if (nbuf == 2) {
+      HIPCHK(hipEventRecord(c->ev_chain[bI], st));
+      HIPCHK(hipStreamWaitEvent(c->side, c->ev_chain[bI], 0));
+      ws_st = c->side;
+    }
     WgradArgs w;
     w.stash_h = a.stash_h; w.stash_dz = a.stash_dz; w.stash_e = a.stash_e; w.graw = a.graw;
     w.rows = (t1 - t0) * TILE;
@@ -475,10 +512,15 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
     rd.partial = partial; rd.partial2 = partial2; rd.n_hidden = N; rd.k0 = c->k0; rd.k0pad = k0ld; rd.n_splits = splits;
     rd.grad = grad_flat; rd.hidden_only = b16 ? 1 : 0; rd.partial_s = partial_s;
     rd.n_small = kSmallBlocks;      // records; every record is written (possibly with zero rows)
-    if (F == 64) rc = b16 ? launch_wgrad16_t<64>(c, w, rd, N, st) : launch_wgrad_t<64>(c, w, rd, N, st);
-    else if (F == 128) rc = b16 ? launch_wgrad16_t<128>(c, w, rd, N, st) : launch_wgrad_t<128>(c, w, rd, N, st);
-    else rc = b16 ? launch_wgrad16_t<256>(c, w, rd, N, st) : launch_wgrad_t<256>(c, w, rd, N, st);
+    if (F == 64) rc = b16 ? launch_wgrad16_t<64>(c, w, rd, N, ws_st) : launch_wgrad_t<64>(c, w, rd, N, ws_st);
+    else if (F == 128) rc = b16 ? launch_wgrad16_t<128>(c, w, rd, N, ws_st) : launch_wgrad_t<128>(c, w, rd, N, ws_st);
+    else rc = b16 ? launch_wgrad16_t<256>(c, w, rd, N, ws_st) : launch_wgrad_t<256>(c, w, rd, N, ws_st);
     if (rc) return rc;
+    if (nbuf == 2) HIPCHK(hipEventRecord(c->ev_wgrad[bI], c->side));
+  }
+  if (nbuf == 2) {       // join: everything on the side stream is ordered before whatever follows on the caller's stream
+    HIPCHK(hipStreamWaitEvent(st, c->ev_wgrad[0], 0));
+    if (ci >= 2) HIPCHK(hipStreamWaitEvent(st, c->ev_wgrad[1], 0));
   }
   return AFX_OK;
 }

@@ -48,6 +48,8 @@ struct ChainArgs {
   float* stash_e;           // [rows, 2*nq]       encoded inputs
   float* graw;              // [rows]             dL/draw
   int64_t stash_rows;
+  int32_t persistent;       // 1: grid = #CUs, workgroups loop over tiles; 0: one workgroup per tile (lets the dispatcher
+                            //    interleave this grid with a concurrent kernel on another stream)
   int32_t fused;            // backward kernel computes pixel, MSE gradient and dL/draw itself (train step)
   const float* target;      // [R] (fused)
   float* pixel;             // [R] out (fused)
