@@ -452,7 +452,7 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
   // the chain kernel of chunk i+1 runs on the caller's stream (one is MFMA/HBM-write heavy, the other HBM-read
   // bound).  Fork/join with events only; the side stream always rejoins the caller's stream before returning.
   int nbuf = 1;
-  if (c->overlap && chunk < tiles && chunk >= 2 * c->n_cu) {
+  if (c->overlap && chunk < tiles && chunk >= 8) {
     if (!c->side) {
       HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
       for (auto& e : c->ev_chain) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));

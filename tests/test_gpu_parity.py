@@ -632,3 +632,33 @@ def test_voxel_projector_vs_scipy(type_ct):
     assert rel_l2(img2.cpu().numpy(), want.numpy()) < 2e-6          # float64 rays, as upstream
     with pytest.raises(ValueError):
         VoxelVolume(np.array([0.0, 1.0, 3.0]), t, t, np.zeros((3, 41, 41)), device=DEV)
+
+
+def test_two_stream_overlap_mode_matches_serial(monkeypatch):
+    """AFX_OVERLAP=1 (weight-gradient kernels of chunk i on a side stream while the chain kernel of chunk i+1 runs,
+    double-buffered stash, non-persistent chain grid) must give the same gradients as the serial schedule."""
+    from nerf_for_angiography_amd.render import train_step_mse
+    from nerf_for_angiography_amd.engine import RenderSpec
+    torch.manual_seed(17)
+    r, s = 3000, 64
+    o = torch.randn(r, 3, device=DEV) * 3 + torch.tensor([0, 0, 1500.0], device=DEV)
+    d = torch.nn.functional.normalize(torch.randn(r, 3, device=DEV) * 0.03 + torch.tensor([0, 0, -1.0], device=DEV), dim=-1)
+    tgt = torch.rand(r, device=DEV)
+    spec = RenderSpec(n_rays=r, n_samples=s, origins=o, dirs=d, mode="acc", t_near=1400.0, t_far=1600.0)
+    results = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("AFX_OVERLAP", mode)
+        torch.manual_seed(3)
+        m = make_model(4, 64, precision="bf16")           # the context reads AFX_OVERLAP when it is created
+        with torch.no_grad():
+            m.output_linear[0].bias.fill_(-5.0)
+        lib = m.engine.lib
+        # a workspace for ~1/3 of the tiles forces several chunks (and with overlap, two half-size stash buffers)
+        fixed = int(lib.afx_query(m.engine.h, 4, 0, 0, 2)) - 32 * 256 * (2 * 5 * 64 * 2 + 64 + 4)
+        m.engine.max_workspace_bytes = fixed + 260 * 256 * (2 * 5 * 64 * 2 + 64 + 4)
+        loss, pix = train_step_mse(m, spec, tgt)
+        torch.cuda.synchronize()
+        results[mode] = (float(loss), pix.clone(), _grads_by_name(m))
+    assert results["0"][0] == results["1"][0] and torch.equal(results["0"][1], results["1"][1])
+    for k, v in results["0"][2].items():
+        assert rel_l2(results["1"][2][k], v) < 1e-5, k
