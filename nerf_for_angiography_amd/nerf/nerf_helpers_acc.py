@@ -8,20 +8,31 @@ from .. import engine as _engine
 
 def acc_ray_marching(radiance_field, grid, scene_aabb, ray_origins, ray_directions, depth_samples_per_ray,
                      near_thresh, far_thresh, early_stop_eps=1e-2, alpha_thre=1e-3):
-    """nerf/nerf_helpers_acc.py:10-31 -> (ray_indices[n], t_starts[n,1], t_ends[n,1]).
+    """nerf/nerf_helpers_acc.py:10-31 -> (ray_indices[n], t_starts[n,1], t_ends[n,1]), packed and ray-sorted.
 
-    grid=None: every ray is marched with the fixed step (far-near)/depth_samples_per_ray, no pruning
-    (the dense variant of model/nerf_helpers_acc.py:29).  Occupancy-grid skipping is not built."""
-    if grid is not None:
-        raise NotImplementedError("occupancy-grid marching (nerfacc.OccupancyGrid) is not built; pass grid=None")
-    dev = ray_origins.device
-    n_rays = ray_origins.shape[0]
-    step = (far_thresh - near_thresh) / depth_samples_per_ray
-    i = torch.arange(depth_samples_per_ray, dtype=torch.float32, device=dev)
-    t_s = torch.tensor(near_thresh, dtype=torch.float32, device=dev) + i * torch.tensor(step, dtype=torch.float32, device=dev)
-    t_e = t_s + torch.tensor(step, dtype=torch.float32, device=dev)
-    ray_indices = torch.arange(n_rays, dtype=torch.int32, device=dev).repeat_interleave(depth_samples_per_ray)
-    return ray_indices, t_s.repeat(n_rays)[:, None], t_e.repeat(n_rays)[:, None]
+    grid=None and scene_aabb=None: every ray is marched with the fixed step (far-near)/depth_samples_per_ray from
+    near_thresh, no pruning (the dense variant of model/nerf_helpers_acc.py:29).  Otherwise the occupancy-grid march
+    of nerf/occupancy.py (restated nerfacc 0.3.x; parity unpinned) with the reference's alpha_fn: sigmoid density at
+    the interval mid-point, alpha = 1 - exp(-sigma * dt)."""
+    render_step_size = (far_thresh - near_thresh) / depth_samples_per_ray
+    if grid is None and scene_aabb is None:
+        dev = ray_origins.device
+        n_rays = ray_origins.shape[0]
+        i = torch.arange(depth_samples_per_ray, dtype=torch.float32, device=dev)
+        t_s = torch.tensor(near_thresh, dtype=torch.float32, device=dev) + i * torch.tensor(render_step_size, dtype=torch.float32, device=dev)
+        t_e = t_s + torch.tensor(render_step_size, dtype=torch.float32, device=dev)
+        ray_indices = torch.arange(n_rays, dtype=torch.int32, device=dev).repeat_interleave(depth_samples_per_ray)
+        return ray_indices, t_s.repeat(n_rays)[:, None], t_e.repeat(n_rays)[:, None]
+
+    def alpha_fn(t_starts, t_ends, ray_indices):
+        positions = ray_origins[ray_indices] + ray_directions[ray_indices] * (t_starts + t_ends) / 2.0
+        sigmas = torch.sigmoid(radiance_field(positions))
+        return 1 - torch.exp(-sigmas * (t_ends - t_starts))
+
+    from .occupancy import ray_marching
+    return ray_marching(ray_origins, ray_directions, scene_aabb=scene_aabb, grid=grid, alpha_fn=alpha_fn,
+                        near_plane=near_thresh, far_plane=far_thresh, early_stop_eps=early_stop_eps,
+                        alpha_thre=alpha_thre, render_step_size=render_step_size)
 
 
 def get_ray_entropy(sigmas, rgb_map, threshold=0.4):
@@ -63,7 +74,12 @@ def acc_render_volume_density(predictions, ray_indices, t_starts, t_ends, n_rays
 
 
 def acc_update_n_step(acc_grid, radiance_field, step, occ_thre=1e-2, inverse=False):
-    """nerf/nerf_helpers_acc.py:65-78.  Without an occupancy grid there is nothing to update."""
-    if acc_grid is not None:
-        raise NotImplementedError("occupancy-grid updates (nerfacc.OccupancyGrid.every_n_step) are not built")
+    """nerf/nerf_helpers_acc.py:65-78: refresh the occupancy grid every 16th step from sigmoid(MLP)."""
+    if acc_grid is None:
+        return acc_grid
+
+    def occ_eval_fn(x):
+        return torch.sigmoid(radiance_field(x))
+
+    acc_grid.every_n_step(step=step, occ_eval_fn=occ_eval_fn, occ_thre=occ_thre)
     return acc_grid

@@ -662,3 +662,45 @@ def test_two_stream_overlap_mode_matches_serial(monkeypatch):
     assert results["0"][0] == results["1"][0] and torch.equal(results["0"][1], results["1"][1])
     for k, v in results["0"][2].items():
         assert rel_l2(results["1"][2][k], v) < 1e-5, k
+
+
+def test_reference_loop_with_occupancy_grid():
+    """The training-iteration body of run_nerf_acc.py:284-306 with the occupancy grid enabled, through the mirrored
+    call surface: grid update, grid-skipping march with early termination (restated nerfacc; unpinned), fused MLP on
+    the packed positions, packed Beer-Lambert product, backward.  The packed result is checked against the CPU oracle
+    on the very same packed samples."""
+    from oracle import angio_oracle as orc
+    from nerf_for_angiography_amd.nerf.nerf_helpers import get_predictions
+    from nerf_for_angiography_amd.nerf.nerf_helpers_acc import acc_ray_marching, acc_render_volume_density, acc_update_n_step
+    from nerf_for_angiography_amd.nerf.occupancy import OccupancyGrid, ContractionType
+    torch.manual_seed(23)
+    m = make_model(4, 64)
+    with torch.no_grad():
+        m.output_linear[0].weight.mul_(8.0)
+        m.output_linear[0].bias.fill_(-4.0)
+    outside = 100.0
+    scene_aabb = torch.tensor([-outside] * 3 + [outside] * 3, dtype=torch.float32, device=DEV)
+    grid = OccupancyGrid(roi_aabb=scene_aabb, resolution=32, contraction_type=ContractionType.AABB).to(DEV)
+    r, s = 500, 100
+    o = torch.tensor([[0.0, 0.0, 1500.0]], device=DEV).repeat(r, 1)
+    d = torch.nn.functional.normalize(torch.randn(r, 3, device=DEV) * 0.03 + torch.tensor([0, 0, -1.0], device=DEV), dim=-1)
+    tgt = torch.rand(r, device=DEV)
+    with torch.no_grad():
+        for n_iter in (0, 16):
+            grid = acc_update_n_step(grid, m, n_iter, occ_thre=1e-4)
+        ri, ts, te = acc_ray_marching(m, grid, scene_aabb, o, d, s, 1400.0, 1600.0, 1e-2, 1e-4)
+    assert 0 < ri.numel() < r * s and bool(torch.all(ri[1:] >= ri[:-1]))
+    pos = o[ri.long()] + d[ri.long()] * (ts + te) / 2.0
+    pred = get_predictions(m, pos, 131072)
+    pix, _ = acc_render_volume_density(pred, ri, ts, te, r, s)
+    loss = torch.nn.functional.mse_loss(pix, tgt)
+    loss.backward()
+    cfg = dict(num_early_layers=4, num_filters=64)
+    params = {k: v.detach().cpu().clone().requires_grad_(k.startswith(("early", "output"))) for k, v in m.state_dict().items()}
+    pred_c = orc.cppn_forward(pos.cpu(), cfg, params)
+    pix_c = orc.acc_render_volume_density(pred_c, ri.cpu(), ts.cpu(), te.cpu(), r)
+    torch.nn.functional.mse_loss(pix_c, tgt.cpu()).backward()
+    assert rel_l2(pix.detach().cpu().numpy(), pix_c.detach().numpy()) < 1e-5
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            assert rel_l2(p.grad.cpu().numpy(), params[k].grad.numpy()) < 1e-4, k
