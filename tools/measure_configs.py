@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Throughput of the BASELINE.json configurations on one MI355X (fills BASELINE.md section 3).
+C2: 256^2 x 64, 8x256; C3: 512^2 x 128 coarse + 64 fine (hierarchical, dense convention), 8x256;
+C4 (1 GPU): 512^2 x 128; C5 (1 GPU): 1024^2 x 256.  fwd+bwd+Adam, bf16, one projection per step."""
+import json, os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np, torch
+from nerf_for_angiography_amd.model.CPPN import CPPN
+from nerf_for_angiography_amd.render import train_step_mse, projection_spec, render_projection, render_rays
+from nerf_for_angiography_amd.nerf.nerf_helpers import fine_sampling
+from nerf_for_angiography_amd.phantomdata.helpers import get_ray_values
+
+dev = torch.device("cuda:0")
+def model(prec="bf16"):
+    torch.manual_seed(0)
+    md = dict(num_early_layers=8, num_late_layers=0, num_filters=256, num_input_channels=3, num_output_channels=1,
+              num_input_channels_views=0, use_bias=True, pos_enc="none", pos_enc_basis=5, act_func="relu", fourier_sigma=5,
+              num_img=1, device=dev, precision=prec)
+    m = CPPN(md).to(dev)
+    with torch.no_grad():
+        m.output_linear[0].weight.mul_(4.0); m.output_linear[0].bias.fill_(-5.0)
+    return m
+
+def timeit(fn, warm=1, steps=3):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / steps
+
+out = {}
+for name, (W, S) in {"C2 256^2x64": (256, 64), "C4 512^2x128 (1 GPU)": (512, 128), "C5 1024^2x256 (1 GPU)": (1024, 256)}.items():
+    m = model(); opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    o, d, m44, _, _ = get_ray_values(20.0, 0.0, 0.0, np.array([0, 0, 1500.0]), W, W, 13.0 * W, dev)
+    pose = torch.from_numpy(m44[None]).to(dev); tgt = torch.rand(W * W, device=dev)
+    spec = projection_spec(pose, W, W, 13.0 * W, S, 1400.0, 1600.0)
+    def step():
+        opt.zero_grad(set_to_none=True); train_step_mse(m, spec, tgt); opt.step()
+    t = timeit(step)
+    out[name] = dict(ms_per_step=round(t * 1e3, 2), ray_samples_per_s=round(W * W * S / t / 1e6, 1))
+    print(name, out[name], flush=True)
+# C3: hierarchical coarse (128) + fine (128 + 64), dense convention with per-ray depths, autograd backward
+W, SC, NF = 512, 128, 64
+m = model(); opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+o, d, m44, _, _ = get_ray_values(20.0, 0.0, 0.0, np.array([0, 0, 1500.0]), W, W, 13.0 * W, dev)
+o, d = o.reshape(-1, 3).float().contiguous(), d.reshape(-1, 3).float().contiguous()
+tgt = torch.rand(W * W, device=dev); z = torch.linspace(1400.0, 1600.0, SC, device=dev)
+def step3():
+    opt.zero_grad(set_to_none=True)
+    with torch.no_grad():
+        coarse = render_rays(m, o, d, mode="dense", z=z, want_aux=True)
+    rgb, dep, ent = fine_sampling(z, coarse.weights, o, d, m, None, NF, 131072)
+    torch.nn.functional.mse_loss(rgb, tgt).backward(); opt.step()
+t = timeit(step3)
+out["C3 512^2x(128 coarse + 192 fine)"] = dict(ms_per_step=round(t * 1e3, 2), ray_samples_per_s=round(W * W * (SC + SC + NF) / t / 1e6, 1))
+print("C3", out["C3 512^2x(128 coarse + 192 fine)"], flush=True)
+# forward-only renders (evaluation): split-bf16 and bf16
+for prec in ("bf16x3", "bf16"):
+    m = model(prec)
+    pose = torch.from_numpy(get_ray_values(20.0, 0.0, 0.0, np.array([0, 0, 1500.0]), 512, 512, 13.0 * 512, dev)[2][None]).to(dev)
+    with torch.no_grad():
+        t = timeit(lambda: render_projection(m, pose, 512, 512, 13.0 * 512, 128, 1400.0, 1600.0))
+    out[f"forward 512^2x128 {prec}"] = dict(ms=round(t * 1e3, 2), ray_samples_per_s=round(512 * 512 * 128 / t / 1e6, 1))
+    print(prec, out[f"forward 512^2x128 {prec}"], flush=True)
+json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out", "configs.json"), "w"), indent=1)
