@@ -14,6 +14,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """Build libafx.so in-tree when it is missing or older than its sources (hipcc cross-compiles gfx950 without a GPU)."""
+    try:
+        from nerf_for_angiography_amd import build as afx_build
+        afx_build.build(force=False)
+    except Exception as exc:          # the library-load test then fails loudly with the reason
+        print(f"[conftest] could not build libafx.so: {exc}")
+
+
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np
