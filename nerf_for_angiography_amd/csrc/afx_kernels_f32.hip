@@ -213,9 +213,10 @@ __global__ void __launch_bounds__(256, 1) k_chain_f32(const ChainArgs a) {
       for (int t = 0; t < NT; ++t) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-          const bool pos = h[t][j] > 0.f;
-          h[t][j] = pos ? h[t][j] : 0.f;
-          if (BWD) mw[t >> 1] |= (pos ? 1u : 0u) << (16 * (t & 1) + j);
+          // integer VALU only (see afx_kernels_bf16.hip): max_i32(bits(x),0) = bits(relu(x)); min_u32(.,1) = [x > 0]
+          const int ri = max(__float_as_int(h[t][j]), 0);
+          h[t][j] = __int_as_float(ri);
+          if (BWD) mw[t >> 1] |= min((uint32_t)ri, 1u) << (16 * (t & 1) + j);
         }
         if (BWD) {
 #pragma unroll
@@ -252,9 +253,9 @@ __global__ void __launch_bounds__(256, 1) k_chain_f32(const ChainArgs a) {
         }
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-          const bool pos = acc[j] > 0.f;
-          hn[t][j] = pos ? acc[j] : 0.f;
-          if (BWD) mw[t >> 1] |= (pos ? 1u : 0u) << (16 * (t & 1) + j);
+          const int ri = max(__float_as_int(acc[j]), 0);
+          hn[t][j] = __int_as_float(ri);
+          if (BWD) mw[t >> 1] |= min((uint32_t)ri, 1u) << (16 * (t & 1) + j);
         }
         if (BWD) {
 #pragma unroll
@@ -326,7 +327,8 @@ __global__ void __launch_bounds__(256, 1) k_chain_f32(const ChainArgs a) {
         for (int q = 0; q < 4; ++q) {
           const f32x4 w4 = wp[q];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) dz[t][4 * q + e] = ((bits >> (4 * q + e)) & 1u) ? w4[e] * g : 0.f;
+          for (int e = 0; e < 4; ++e)
+            dz[t][4 * q + e] = __int_as_float(__float_as_int(w4[e] * g) & (((int)(bits << (31 - (4 * q + e)))) >> 31));
         }
       }
       for (int l = N; l >= 1; --l) {
@@ -351,7 +353,7 @@ __global__ void __launch_bounds__(256, 1) k_chain_f32(const ChainArgs a) {
           }
           const uint32_t bits = mk[((l - 1) * MW + (t >> 1)) * 256 + tid] >> (16 * (t & 1));
 #pragma unroll
-          for (int j = 0; j < 16; ++j) dn[t][j] = ((bits >> j) & 1u) ? acc[j] : 0.f;
+          for (int j = 0; j < 16; ++j) dn[t][j] = __int_as_float(__float_as_int(acc[j]) & (((int)(bits << (31 - j))) >> 31));
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) dz[t] = dn[t];
