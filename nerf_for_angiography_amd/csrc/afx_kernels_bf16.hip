@@ -68,7 +68,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
   constexpr int MW = (NT + 1) / 2;
   constexpr int TS = NW * 32 * NCG;        // samples per workgroup tile
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, hh = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, col = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform: scalar branches, no exec masking
   const int N = a.n_hidden;
   if (a.tile0 + (int)blockIdx.x >= a.tile1) return;
 
