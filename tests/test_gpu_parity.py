@@ -704,3 +704,47 @@ def test_reference_loop_with_occupancy_grid():
     for k, p in m.named_parameters():
         if p.grad is not None:
             assert rel_l2(p.grad.cpu().numpy(), params[k].grad.numpy()) < 1e-4, k
+
+
+@pytest.mark.parametrize("layers,width,n_samples,n_rays", [(1, 64, 2, 1), (2, 128, 33, 7), (12, 64, 32, 40), (3, 256, 5, 3),
+                                                              (5, 128, 96, 257)])
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_odd_shapes_vs_oracle(layers, width, n_samples, n_rays, prec):
+    """Edge geometry: a single ray, 2 samples, sample counts that are not multiples of 32, 1 and 12 hidden layers, ray
+    counts that leave most of the last workgroup tile empty."""
+    from oracle import angio_oracle as orc
+    from nerf_for_angiography_amd.render import render_rays
+    torch.manual_seed(layers * 1000 + width + n_samples)
+    m = make_model(layers, width, precision=prec)
+    with torch.no_grad():
+        m.output_linear[0].weight.mul_(4.0)
+        m.output_linear[0].bias.fill_(-3.0)
+    o = torch.tensor([[0.0, 0.0, 1500.0]]).repeat(n_rays, 1) + torch.randn(n_rays, 3)
+    d = torch.nn.functional.normalize(torch.randn(n_rays, 3) * 0.03 + torch.tensor([0, 0, -1.0]), dim=-1)
+    tgt = torch.rand(n_rays)
+    cfg = dict(num_early_layers=layers, num_filters=width)
+    params = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    pix_c, _, grads_c = orc.loss_and_grads(o, d, tgt, cfg, params, near=1450.0, far=1550.0, n_samples=n_samples, convention="acc")
+    out = render_rays(m, o.to(DEV), d.to(DEV), n_samples, 1450.0, 1550.0, mode="acc")
+    torch.nn.functional.mse_loss(out.rgb_map, tgt.to(DEV)).backward()
+    assert out.rgb_map.shape == (n_rays,)
+    # few, thick steps (dt up to 50) give plain bf16 no averaging over samples: its error bar is 4x wider here
+    loose = 4 if prec == "bf16" else 1
+    assert rel_l2(out.rgb_map.detach().cpu().numpy(), pix_c.numpy()) < loose * TOL[prec]["pix"]
+    got = _grads_by_name(m)
+    for k, v in grads_c.items():
+        if float(v.abs().max()) > 0:
+            assert rel_l2(got[k], v.numpy()) < 2 * loose * TOL[prec]["grad"], k
+
+
+def test_model_too_deep_for_lds_is_refused():
+    """16 hidden layers of width 256 need more ReLU-mask LDS than a CU has: a clear error, not a crash."""
+    from nerf_for_angiography_amd.render import render_rays
+    from nerf_for_angiography_amd._lib import AfxError
+    m = make_model(16, 256, precision="bf16")
+    o = torch.zeros(8, 3, device=DEV)
+    with torch.no_grad():
+        assert render_rays(m, o, o + 1, 32, 0.0, 1.0).rgb_map.shape == (8,)          # forward needs no masks
+    out = render_rays(m, o, o + 1, 32, 0.0, 1.0)
+    with pytest.raises(AfxError, match="LDS"):
+        out.rgb_map.sum().backward()
