@@ -671,11 +671,26 @@ __global__ void __launch_bounds__(256) k_small_grads_bf16(const WgradArgs a) {
   if (blockIdx.y == 0 && threadIdx.x == 0) P[(size_t)F * a.k0pad + 2 * F] = vg;
 }
 
+// grid = ceil(SS/64) blocks of 64 x 4 threads: 4 record groups per element (fixed-order partial sums, combined in
+// fixed order through LDS), so that the ~5 MB reduction spreads over the whole chip instead of 18 workgroups.
 template <int F>
-__global__ void k_reduce_small(const ReduceArgs a) {
+__global__ void __launch_bounds__(256) k_reduce_small(const ReduceArgs a) {
+  __shared__ float red[4][64];
   const size_t SS = (size_t)F * a.k0pad + 2 * F + 4;
-  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (e > (size_t)F * a.k0pad + 2 * F) return;
+  const size_t e = (size_t)blockIdx.x * 64 + threadIdx.x;
+  const int grp = threadIdx.y;
+  const bool valid = e <= (size_t)F * a.k0pad + 2 * F;
+  float s = 0.f;
+  if (valid) {
+    const int per = (a.n_small + 3) / 4;
+    const int b1 = min((grp + 1) * per, a.n_small);
+#pragma unroll 8
+    for (int b = grp * per; b < b1; ++b) s += a.partial_s[(size_t)b * SS + e];
+  }
+  red[grp][threadIdx.x] = s;
+  __syncthreads();
+  if (grp != 0 || !valid) return;
+  s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
   const size_t wout = (size_t)F * a.k0 + F + (size_t)a.n_hidden * ((size_t)F * F + F);
   size_t dst;
   if (e < (size_t)F * a.k0pad) {
@@ -684,8 +699,6 @@ __global__ void k_reduce_small(const ReduceArgs a) {
     dst = (size_t)row * a.k0 + c;
   } else if (e < (size_t)F * a.k0pad + F) dst = (size_t)F * a.k0 + (e - (size_t)F * a.k0pad);
   else dst = wout + (e - (size_t)F * a.k0pad - F);       // F output weights, then the output bias
-  float s = 0.f;
-  for (int b = 0; b < a.n_small; ++b) s += a.partial_s[(size_t)b * SS + e];
   a.grad[dst] += s;
 }
 
