@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
     for (int cg = 0; cg < NCG; ++cg) dot[cg] = 0.f;
 
     // epilogue of one output tile: ReLU, (mask), next fragments, (stash), output-layer dot product
-    auto epilogue = [&](int l, int t, const f32x16& acc, int cg, u32x4* nf, u32x4* nl, uint32_t* mw) {
+    auto epilogue = [&](int l, int t, const f32x16& acc, int cg, u32x4* nf, u32x4* nl) {
       // ReLU and its mask with integer VALU ops only (no compare -> SGPR lane masks, which hipcc spills here):
       // for a non-NaN float x, max_i32(bits(x), 0) is bits(relu(x)), and min_u32(that, 1) is [x > 0].
       float v[16];
@@ -264,9 +264,6 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
 
     // ---------------- layer 0 (always split: hi*hi + hi*lo + lo*hi)
     {
-      uint32_t mw[MW * NCG];
-#pragma unroll
-      for (int w = 0; w < MW * NCG; ++w) mw[w] = 0;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const u32x4* sl = step_begin();           // [(q*2 + part)*64 + lane]
@@ -284,16 +281,13 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
           }
         }
 #pragma unroll
-        for (int cg = 0; cg < NCG; ++cg) epilogue(0, t, acc[cg], cg, hf[cg][t], hl[X3 ? cg : 0][X3 ? t : 0], mw);
+        for (int cg = 0; cg < NCG; ++cg) epilogue(0, t, acc[cg], cg, hf[cg][t], hl[X3 ? cg : 0][X3 ? t : 0]);
       }
     }
     // ---------------- hidden layers
     for (int l = 1; l <= N; ++l) {
       u32x4 nf[NCG][NT][2];
       u32x4 nl[X3 ? NCG : 1][X3 ? NT : 1][2];
-      uint32_t mw[MW * NCG];
-#pragma unroll
-      for (int w = 0; w < MW * NCG; ++w) mw[w] = 0;
       // Forward-only kernels defer the epilogue of tile t-1 into step t (behind that step's MFMAs, which do
       // not depend on it) so the VALU work overlaps the matrix pipe.  The backward kernel keeps each
       // epilogue in its own step: its stash stores are what the step's vmcnt(SPS) counts.
@@ -310,19 +304,19 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
           if (t > 0) {
 #pragma unroll
             for (int cg = 0; cg < NCG; ++cg)
-              epilogue(l, t - 1, accp[cg], cg, nf[cg][t > 0 ? t - 1 : 0], nl[X3 ? cg : 0][X3 && t > 0 ? t - 1 : 0], mw);
+              epilogue(l, t - 1, accp[cg], cg, nf[cg][t > 0 ? t - 1 : 0], nl[X3 ? cg : 0][X3 && t > 0 ? t - 1 : 0]);
           }
 #pragma unroll
           for (int cg = 0; cg < NCG; ++cg) accp[cg] = acc[cg];
         } else {
 #pragma unroll
-          for (int cg = 0; cg < NCG; ++cg) epilogue(l, t, acc[cg], cg, nf[cg][t], nl[X3 ? cg : 0][X3 ? t : 0], mw);
+          for (int cg = 0; cg < NCG; ++cg) epilogue(l, t, acc[cg], cg, nf[cg][t], nl[X3 ? cg : 0][X3 ? t : 0]);
         }
       }
       if (DEFER) {
 #pragma unroll
         for (int cg = 0; cg < NCG; ++cg)
-          epilogue(l, NT - 1, accp[cg], cg, nf[cg][NT - 1], nl[X3 ? cg : 0][X3 ? NT - 1 : 0], mw);
+          epilogue(l, NT - 1, accp[cg], cg, nf[cg][NT - 1], nl[X3 ? cg : 0][X3 ? NT - 1 : 0]);
       }
 #pragma unroll
       for (int cg = 0; cg < NCG; ++cg)
