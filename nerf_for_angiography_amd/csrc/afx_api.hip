@@ -321,6 +321,7 @@ static void fill_model(const afx_ctx* c, int prec, bool bwd, const void* prepare
   // the backward kernel of the split mode recomputes in plain bf16: it streams only the hi halves
   a.slabh_bytes = (prec == AFX_PREC_BF16X3 && bwd) ? L.slabt_bytes : L.slabh_stride;
   a.slot_bytes = a.slab0_bytes > a.slabh_bytes ? a.slab0_bytes : a.slabh_bytes;
+  if (is_bf16(prec) && c->nt >= 2) a.slot_bytes *= 2;      // bf16 chain kernels process two output tiles per step
   a.n_hidden = c->d.n_hidden; a.k0 = c->k0; a.nq = c->nq; a.enc = c->d.enc; a.n_freq = c->d.n_freq;
   a.persistent = 1;
 }

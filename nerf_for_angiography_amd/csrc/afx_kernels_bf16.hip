@@ -94,39 +94,44 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
       if (off + (uint32_t)wave * 1024u < BYTES)
         __builtin_amdgcn_global_load_lds(GPTR(src + off + wave * 1024 + lane * 16), LPTR(dst + off + wave * 1024), 16, 0, 0);
   };
-  const int nfwd = NT * (N + 1);
-  const int steps_per_tile = nfwd + (BWD ? NT * N : 0);
+  // A step covers TPS consecutive 32-row output tiles of one layer (one barrier, one DMA batch per TPS tiles).
+  constexpr int TPS = NT >= 2 ? 2 : 1;
+  constexpr int SPL = NT / TPS;                       // steps per layer
+  const int nfwd = SPL * (N + 1);
+  const int steps_per_tile = nfwd + (BWD ? SPL * N : 0);
   int seq = 0;
   uint32_t par = 0;
   bool has_next = false;
-  // Step protocol: wait for THIS step's slab (LDS-DMA issued one step ago), barrier (which also retires
-  // every reader of the other slot), start the DMA of the next slab, compute.  In the backward kernel
+  // Step protocol: wait for THIS step's slabs (LDS-DMA issued one step ago), barrier (which also retires
+  // every reader of the other slot), start the DMA of the next step's slabs, compute.  In the backward kernel
   // each step issues exactly SPS stash stores AFTER its DMA; vmcnt counts in issue order, so vmcnt(SPS)
   // retires the DMA while the step's own stores stay in flight (a vmcnt(0) here costs a full store
   // round-trip per step).  Raw s_barrier: __syncthreads() would re-insert vmcnt(0).
-  constexpr int SPS = 2 * NCG;
+  constexpr int SPS = 2 * NCG * TPS;
   bool first_step = true;
-  auto step_begin = [&]() -> const u32x4* {
-    if (BWD && !first_step && !(a.debug & 15)) {
-      if (SPS == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
-    } else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  auto step_begin = [&]() -> const char* {
+    if (BWD && !first_step && !(a.debug & 15)) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(SPS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     first_step = false;
     int ni = seq + 1;
     bool doload = true;
     if (ni == steps_per_tile) { ni = 0; doload = has_next; }
     if (doload) {
       char* dst = slot0 + (par ^ 1u) * (size_t)a.slot_bytes;
-      if (ni < NT) dma(a.stream_fwd + (size_t)ni * SLAB0, dst, std::integral_constant<uint32_t, SLAB0>{});
-      else if (ni < nfwd) dma(a.stream_fwd + (size_t)NT * SLAB0 + (size_t)(ni - NT) * a.slabh_stride, dst, std::integral_constant<uint32_t, LOADH>{});
-      else dma(a.stream_bwd + (size_t)(ni - nfwd) * SLABT, dst, std::integral_constant<uint32_t, SLABT>{});
+#pragma unroll
+      for (int k = 0; k < TPS; ++k) {
+        if (ni < SPL) dma(a.stream_fwd + (size_t)(ni * TPS + k) * SLAB0, dst + k * SLAB0, std::integral_constant<uint32_t, SLAB0>{});
+        else if (ni < nfwd) dma(a.stream_fwd + (size_t)NT * SLAB0 + (size_t)((ni - SPL) * TPS + k) * a.slabh_stride, dst + k * LOADH, std::integral_constant<uint32_t, LOADH>{});
+        else dma(a.stream_bwd + (size_t)((ni - nfwd) * TPS + k) * SLABT, dst + k * SLABT, std::integral_constant<uint32_t, SLABT>{});
+      }
     }
     const char* cur = slot0 + par * (size_t)a.slot_bytes;
     par ^= 1u;
     seq = ni;
-    return (const u32x4*)cur;
+    return cur;
   };
-  dma(a.stream_fwd, slot0, std::integral_constant<uint32_t, SLAB0>{});
+#pragma unroll
+  for (int k = 0; k < TPS; ++k) dma(a.stream_fwd + (size_t)k * SLAB0, slot0 + k * SLAB0, std::integral_constant<uint32_t, SLAB0>{});
 
   for (int tile = a.tile0 + blockIdx.x; tile < a.tile1; tile += gridDim.x) {
     has_next = tile + (int)gridDim.x < a.tile1;
@@ -158,6 +163,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
       }
     }
 
+    const char* stepbase = nullptr;      // LDS slot of the current step
     u32x4 hf[NCG][NT][2];
     u32x4 hl[X3 ? NCG : 1][X3 ? NT : 1][2];
     float dot[NCG];
@@ -266,7 +272,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
     {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const u32x4* sl = step_begin();           // [(q*2 + part)*64 + lane]
+        if (t % TPS == 0) stepbase = step_begin();
+        const u32x4* sl = (const u32x4*)(stepbase + (t % TPS) * SLAB0);     // [(q*2 + part)*64 + lane]
         f32x16 acc[NCG];
 #pragma unroll
         for (int cg = 0; cg < NCG; ++cg) acc[cg] = bias_init(0, t);
@@ -295,7 +302,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
       f32x16 accp[NCG];
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const u32x4* sl = step_begin();           // hi block [u*64 + lane], then lo block (X3)
+        if (t % TPS == 0) stepbase = step_begin();
+        const u32x4* sl = (const u32x4*)(stepbase + (t % TPS) * LOADH);     // hi block [u*64 + lane], then lo block (X3)
         f32x16 acc[NCG];
 #pragma unroll
         for (int cg = 0; cg < NCG; ++cg) acc[cg] = bias_init(l, t);
@@ -436,7 +444,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
         u32x4 dn[NCG][NT][2];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          const u32x4* sl = step_begin();
+          if (t % TPS == 0) stepbase = step_begin();
+          const u32x4* sl = (const u32x4*)(stepbase + (t % TPS) * SLABT);
           stash_dz_tile(l, t);                   // SPS stores per step, after the step's DMA
           f32x16 acc[NCG];
 #pragma unroll
