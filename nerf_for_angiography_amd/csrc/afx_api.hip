@@ -63,7 +63,7 @@ static inline size_t rup64(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // Layout of the prepared-weights buffer for one precision.
 struct PrepLayout {
   uint32_t small_floats, small_bytes_pad, slab0_bytes, slabh_stride, slabt_bytes;
-  uint32_t small_off, slab0_off, fwd_off, bwd_off;
+  uint32_t small_off, slab0_off, fwd_off, bwd_off, lo_off;
   int n_slab0;          // slabs of the first layer in the forward stream (1 for f32, NT for bf16)
   size_t total;
 };
@@ -91,11 +91,13 @@ static PrepLayout prep_layout(const afx_ctx* c, int prec) {
     L.n_slab0 = NT;
     L.slab0_bytes = rup((uint64_t)nk0_of(c) * 2 * 1024, 4096);
     L.slabt_bytes = (uint32_t)NT * 2 * 1024;
-    L.slabh_stride = (prec == AFX_PREC_BF16X3 ? 2u : 1u) * L.slabt_bytes;
+    L.slabh_stride = L.slabt_bytes;
   }
-  L.fwd_off = L.slab0_off + (uint32_t)L.n_slab0 * L.slab0_bytes;   // contiguous: one forward stream
+  // [first-layer slabs | forward hidden slabs | transposed slabs] is one contiguous stream in consumption order
+  L.fwd_off = L.slab0_off + (uint32_t)L.n_slab0 * L.slab0_bytes;
   L.bwd_off = L.fwd_off + (uint32_t)N * NT * L.slabh_stride;
-  L.total = (size_t)L.bwd_off + (size_t)N * NT * L.slabt_bytes;
+  L.lo_off = L.bwd_off + (uint32_t)N * NT * L.slabt_bytes;         // split-bf16: lo parts of the forward hidden slabs
+  L.total = (size_t)L.lo_off + (prec == AFX_PREC_BF16X3 ? (size_t)N * NT * L.slabt_bytes : 0);
   return L;
 }
 
@@ -252,7 +254,7 @@ extern "C" int afx_prepare_weights(afx_ctx* c, int prec, const float* params, co
     q.params = params; q.prepared = (char*)prepared;
     q.F = c->d.width; q.n_hidden = c->d.n_hidden; q.k0 = c->k0; q.nk0 = nk0_of(c); q.parts = prec == AFX_PREC_BF16X3 ? 2 : 1;
     q.slab0_off = L.slab0_off; q.slab0_bytes = L.slab0_bytes; q.fwd_off = L.fwd_off; q.slabh_stride = L.slabh_stride;
-    q.bwd_off = L.bwd_off; q.slabt_bytes = L.slabt_bytes;
+    q.bwd_off = L.bwd_off; q.slabt_bytes = L.slabt_bytes; q.lo_off = L.lo_off;
     hipLaunchKernelGGL(k_prepare_bf16, dim3(512), dim3(256), 0, (hipStream_t)stream, q);
   }
   HIPCHK(hipGetLastError());
@@ -315,13 +317,14 @@ static void fill_model(const afx_ctx* c, int prec, bool bwd, const void* prepare
   const char* base = (const char*)prepared;
   a.stream_fwd = base + L.slab0_off;
   a.stream_bwd = base + L.bwd_off;
+  a.stream_lo = base + L.lo_off;
   a.small = (const float*)(base + L.small_off);
   a.small_floats = L.small_floats; a.small_bytes_pad = L.small_bytes_pad;
   a.slab0_bytes = L.slab0_bytes; a.slabh_stride = L.slabh_stride; a.slabt_bytes = L.slabt_bytes;
-  // the backward kernel of the split mode recomputes in plain bf16: it streams only the hi halves
-  a.slabh_bytes = (prec == AFX_PREC_BF16X3 && bwd) ? L.slabt_bytes : L.slabh_stride;
+  a.slabh_bytes = L.slabh_stride;
   a.slot_bytes = a.slab0_bytes > a.slabh_bytes ? a.slab0_bytes : a.slabh_bytes;
-  if (is_bf16(prec) && c->nt >= 2) a.slot_bytes *= 2;      // bf16 chain kernels process two output tiles per step
+  // the backward kernel of the split mode recomputes in plain bf16: it streams only the hi parts
+  if (is_bf16(prec)) a.slot_bytes = chain_slot_bytes(c->nt, nk0_of(c), bwd, prec == AFX_PREC_BF16X3 && !bwd);
   a.n_hidden = c->d.n_hidden; a.k0 = c->k0; a.nq = c->nq; a.enc = c->d.enc; a.n_freq = c->d.n_freq;
   a.persistent = 1;
 }

@@ -8,11 +8,23 @@ namespace afx {
 constexpr int TILE = 128;            // samples per workgroup tile (4 waves x 32 sample-columns)
 constexpr int GROUP = 32;            // samples per wave column group; s_pad is a multiple of this
 
+// Geometry of the bf16 chain kernels' weight ring, shared by the kernels and the host (LDS size, prepared layout).
+// A step streams TPS consecutive 32-row output tiles of one layer into one LDS slot.  The backward kernel keeps its
+// ReLU masks in LDS, which leaves room for 2 tiles per step; forward-only kernels take 4.
+constexpr int chain_tps(int nt, bool bwd, bool x3) { return (nt >= 4 && !bwd && !x3) ? 4 : (nt >= 2 ? 2 : 1); }
+constexpr uint32_t chain_slab0_bytes(int nk0) { return ((uint32_t)nk0 * 2048u + 4095u) / 4096u * 4096u; }
+constexpr uint32_t chain_slot_bytes(int nt, int nk0, bool bwd, bool x3) {
+  const uint32_t s0 = (uint32_t)chain_tps(nt, bwd, x3) * chain_slab0_bytes(nk0);
+  const uint32_t sh = (uint32_t)chain_tps(nt, bwd, x3) * (uint32_t)nt * 2048u * (x3 ? 2u : 1u);
+  return s0 > sh ? s0 : sh;
+}
+
 // Arguments of the fused chain kernels (by value, < 512 B).
 struct ChainArgs {
   // prepared weights
   const char* stream_fwd;   // slab0, then n_hidden*NT forward slabs (layer 1..N, tile 0..NT-1)
-  const char* stream_bwd;   // n_hidden*NT transposed slabs (layer N..1, tile 0..NT-1)
+  const char* stream_bwd;   // n_hidden*NT transposed slabs (layer N..1, tile 0..NT-1); bf16: directly behind stream_fwd
+  const char* stream_lo;    // split-bf16 only: the lo parts of the forward hidden slabs, same order as the hi parts
   const float* small;       // permuted biases, output weights, bout, encoding aux
   uint32_t small_floats;    // multiple of 4
   uint32_t small_bytes_pad; // LDS bytes reserved for `small` (multiple of 1024)

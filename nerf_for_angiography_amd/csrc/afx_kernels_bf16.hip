@@ -55,7 +55,28 @@ template <int F> __device__ __forceinline__ uint32_t stash_off(uint32_t r, int c
 // 16-byte stash store, non-temporal: the stash is written once and read once by another kernel, so it must not
 // displace the weight slabs every workgroup re-streams from L2.  A/B in one process on the 512^2x128 step,
 // k_chain<bwd>: plain 116 ms, nt 99 ms, sc1 (write-through) 121 ms.
-__device__ __forceinline__ void stash_store(char* p, u32x4 v, int) { __builtin_nontemporal_store(v, (u32x4*)p); }
+__device__ __forceinline__ void stash_store(char* p, u32x4 v) { __builtin_nontemporal_store(v, (u32x4*)p); }
+
+// Packed-bf16 epilogue helpers.  The bf16 sign bit is the int16 sign bit, so ReLU of two packed values is
+// one v_pk_max_i16, [h != 0] per half one v_pk_min_u16, and a per-half 0xffff/0 mask from bit q of each
+// half is v_pk_lshlrev_b16 + v_pk_ashrrev_i16: half the VALU work of the same operations on fp32 values.
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned relu2(unsigned p) {
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p), (s16x2){0, 0}));
+}
+__device__ __forceinline__ unsigned nz2(unsigned p) {
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(u16x2, p), (u16x2){1, 1}));
+}
+__device__ __forceinline__ unsigned halfmask(unsigned b, int q) {
+  s16x2 v = __builtin_bit_cast(s16x2, b);
+  v = v << (short)(15 - q);
+  v = v >> (short)15;
+  return __builtin_bit_cast(unsigned, v);
+}
+// ReLU masks of one 32-row tile: 16 bits per lane.  Bit q = [element 2q > 0], bit 8+q = [element 2q+1 > 0]
+// (elements as rounded to bf16).  mask_expand() moves the two bytes to the two halves of a dword for halfmask().
+__device__ __forceinline__ unsigned mask_expand(unsigned b16) { return (b16 & 0xffu) | ((b16 & 0xff00u) << 8); }
 
 template <int F, bool X3, bool ENC, bool BWD, int NW>
 __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs a) {
@@ -73,65 +94,81 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
   const int N = a.n_hidden;
   if (a.tile0 + (int)blockIdx.x >= a.tile1) return;
 
+  // A step covers TPS consecutive 32-row output tiles of one layer: one barrier and one LDS-DMA batch per step.
+  constexpr int TPS = chain_tps(NT, BWD, X3);
+  constexpr int SPL = NT / TPS;                       // steps per layer
+  static_assert(NT % TPS == 0, "");
+  // slab sizes are fixed by the template parameters (the host lays the prepared buffer out identically)
+  constexpr uint32_t SLAB0 = chain_slab0_bytes(NK0);                  // first-layer slab: NK0 x (hi,lo) KiB
+  constexpr uint32_t SLABT = NT * 2048u;                              // one hidden slab part (hi or lo)
+  constexpr uint32_t STEP0 = TPS * SLAB0, STEPH = TPS * SLABT;        // bytes one step streams (X3: STEPH hi + STEPH lo)
+  constexpr uint32_t SLOT = chain_slot_bytes(NT, NK0, BWD, X3);
+
+  char* slot0 = lds + a.small_bytes_pad;
+  // The prepared buffer holds [first-layer slabs | forward hidden slabs (hi) | transposed slabs] as ONE contiguous
+  // stream in the order a tile consumes it (the lo parts of the split mode are a second stream): the source of the
+  // next step is a running scalar pointer, and every step is a straight-line run of 1 KiB LDS-DMA pieces.
+  const char* wnext = a.stream_fwd;
+  const char* lnext = a.stream_lo;
+  const uint32_t voff = (uint32_t)wave * 1024u + (uint32_t)lane * 16u;
+  auto dma_run = [&](const char* src, char* dst, auto bytes_c) {
+    constexpr uint32_t BYTES = decltype(bytes_c)::value;
+    static_assert(BYTES % (NW * 1024u) == 0, "a step is a whole number of pieces per wave");
+#pragma unroll
+    for (uint32_t off = 0; off < BYTES; off += NW * 1024u)
+      __builtin_amdgcn_global_load_lds(GPTR(src + off + voff), LPTR(dst + off + wave * 1024), 16, 0, 0);
+  };
+  dma_run(wnext, slot0, std::integral_constant<uint32_t, STEP0>{});
+  wnext += STEP0;
+
   float* sm = (float*)lds;
   for (uint32_t i = tid * 4; i < a.small_floats; i += NTH * 4) *(f32x4*)(sm + i) = *(const f32x4*)(a.small + i);
-  char* slot0 = lds + a.small_bytes_pad;
-  uint32_t* mk = (uint32_t*)(slot0 + 2 * (size_t)a.slot_bytes);   // ReLU masks, 16 bits per (layer, tile, column group, thread)
-  unsigned short* mk16 = (unsigned short*)mk;                     // [((l*NT + t)*NCG + cg)*NTH + tid]
+  unsigned short* mk16 = (unsigned short*)(slot0 + 2 * (size_t)SLOT);   // ReLU masks [((l*NT + t)*NCG + cg)*NTH + tid]
   const float* bias_perm = sm;
   const float* wout_perm = sm + (N + 1) * F;
   const float* aux = sm + (N + 2) * F + 4;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the first step's slabs: every later step counts (below)
   __syncthreads();
 
-  // slab sizes are fixed by the template parameters (the host lays the prepared buffer out identically)
-  constexpr uint32_t SLAB0 = (NK0 * 2048u + 4095u) / 4096u * 4096u;   // first-layer slab: NK0 x (hi,lo) KiB
-  constexpr uint32_t SLABT = NT * 2048u;                              // one hidden slab part (hi or lo)
-  constexpr uint32_t LOADH = X3 ? 2 * SLABT : SLABT;                  // bytes of a forward hidden slab this kernel reads
-  auto dma = [&](const char* src, char* dst, auto bytes_c) {
-    constexpr uint32_t BYTES = decltype(bytes_c)::value;
-#pragma unroll
-    for (uint32_t off = 0; off < BYTES; off += NW * 1024u)
-      if (off + (uint32_t)wave * 1024u < BYTES)
-        __builtin_amdgcn_global_load_lds(GPTR(src + off + wave * 1024 + lane * 16), LPTR(dst + off + wave * 1024), 16, 0, 0);
-  };
-  // A step covers TPS consecutive 32-row output tiles of one layer (one barrier, one DMA batch per TPS tiles).
-  constexpr int TPS = NT >= 2 ? 2 : 1;
-  constexpr int SPL = NT / TPS;                       // steps per layer
-  const int nfwd = SPL * (N + 1);
-  const int steps_per_tile = nfwd + (BWD ? SPL * N : 0);
-  int seq = 0;
   uint32_t par = 0;
   bool has_next = false;
   // Step protocol: wait for THIS step's slabs (LDS-DMA issued one step ago), barrier (which also retires
   // every reader of the other slot), start the DMA of the next step's slabs, compute.  In the backward kernel
-  // each step issues exactly SPS stash stores AFTER its DMA; vmcnt counts in issue order, so vmcnt(SPS)
+  // each step issues at least SPS stash stores AFTER its DMA; vmcnt counts in issue order, so vmcnt(SPS)
   // retires the DMA while the step's own stores stay in flight (a vmcnt(0) here costs a full store
   // round-trip per step).  Raw s_barrier: __syncthreads() would re-insert vmcnt(0).
   constexpr int SPS = 2 * NCG * TPS;
-  bool first_step = true;
-  auto step_begin = [&]() -> const char* {
-    if (BWD && !first_step && !(a.debug & 15)) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(SPS) : "memory");
+  constexpr std::integral_constant<int, 0> K_L0{};     // the next step is a first-layer step
+  constexpr std::integral_constant<int, 1> K_FWD{};    // ... a hidden forward step
+  constexpr std::integral_constant<int, 2> K_BWD{};    // ... a transposed (input-gradient) step
+  auto step_begin = [&](auto next_c, bool doload) -> const char* {
+    constexpr int NEXT = decltype(next_c)::value;
+    if (BWD) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(SPS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    first_step = false;
-    int ni = seq + 1;
-    bool doload = true;
-    if (ni == steps_per_tile) { ni = 0; doload = has_next; }
     if (doload) {
-      char* dst = slot0 + (par ^ 1u) * (size_t)a.slot_bytes;
-#pragma unroll
-      for (int k = 0; k < TPS; ++k) {
-        if (ni < SPL) dma(a.stream_fwd + (size_t)(ni * TPS + k) * SLAB0, dst + k * SLAB0, std::integral_constant<uint32_t, SLAB0>{});
-        else if (ni < nfwd) dma(a.stream_fwd + (size_t)NT * SLAB0 + (size_t)((ni - SPL) * TPS + k) * a.slabh_stride, dst + k * LOADH, std::integral_constant<uint32_t, LOADH>{});
-        else dma(a.stream_bwd + (size_t)((ni - nfwd) * TPS + k) * SLABT, dst + k * SLABT, std::integral_constant<uint32_t, SLABT>{});
+      char* dst = slot0 + (par ^ 1u) * SLOT;
+      if constexpr (NEXT == 0) {
+        dma_run(wnext, dst, std::integral_constant<uint32_t, STEP0>{});
+        wnext += STEP0;
+      } else {
+        dma_run(wnext, dst, std::integral_constant<uint32_t, STEPH>{});
+        wnext += STEPH;
+        if constexpr (X3 && NEXT == 1) {
+          dma_run(lnext, dst + STEPH, std::integral_constant<uint32_t, STEPH>{});
+          lnext += STEPH;
+        }
       }
     }
-    const char* cur = slot0 + par * (size_t)a.slot_bytes;
+    const char* cur = slot0 + par * SLOT;
     par ^= 1u;
-    seq = ni;
     return cur;
   };
-#pragma unroll
-  for (int k = 0; k < TPS; ++k) dma(a.stream_fwd + (size_t)k * SLAB0, slot0 + k * SLAB0, std::integral_constant<uint32_t, SLAB0>{});
+  // last step of a tile: the stream restarts with the next tile's first-layer slabs
+  auto step_begin_wrap = [&]() -> const char* {
+    wnext = a.stream_fwd;
+    lnext = a.stream_lo;
+    return step_begin(K_L0, has_next);
+  };
 
   for (int tile = a.tile0 + blockIdx.x; tile < a.tile1; tile += gridDim.x) {
     has_next = tile + (int)gridDim.x < a.tile1;
@@ -172,40 +209,42 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
 
     // epilogue of one output tile: ReLU, (mask), next fragments, (stash), output-layer dot product
     auto epilogue = [&](int l, int t, const f32x16& acc, int cg, u32x4* nf, u32x4* nl) {
-      // ReLU and its mask with integer VALU ops only (no compare -> SGPR lane masks, which hipcc spills here):
-      // for a non-NaN float x, max_i32(bits(x), 0) is bits(relu(x)), and min_u32(that, 1) is [x > 0].
-      float v[16];
-      uint32_t bits = 0;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const int ri = max(__float_as_int(acc[j]), 0);
-        v[j] = __int_as_float(ri);
-        if (BWD) bits |= min((uint32_t)ri, 1u) << j;
-      }
-      if (BWD) mk16[((l * NT + t) * NCG + cg) * NTH + tid] = (unsigned short)bits;   // 16 ReLU bits per tile, written at once
-      if (l == N) {
+      if (l == N) {       // the output layer (width -> 1) reads the fp32 activations
         const f32x4* wp = (const f32x4*)(wout_perm + (hh * NT + t) * 16);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const f32x4 w4 = wp[q];
-          dot[cg] = fmaf(v[4 * q + 0], w4[0], dot[cg]);
-          dot[cg] = fmaf(v[4 * q + 1], w4[1], dot[cg]);
-          dot[cg] = fmaf(v[4 * q + 2], w4[2], dot[cg]);
-          dot[cg] = fmaf(v[4 * q + 3], w4[3], dot[cg]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            dot[cg] = fmaf(__int_as_float(max(__float_as_int(acc[4 * q + e]), 0)), w4[e], dot[cg]);
         }
       }
+      if constexpr (X3) {
+        float v[16];
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        if (X3) split_frag(v + 8 * s, nf[s], nl[s]);
-        else {
+        for (int j = 0; j < 16; ++j) v[j] = __int_as_float(max(__float_as_int(acc[j]), 0));
+        split_frag(v, nf[0], nl[0]);
+        split_frag(v + 8, nf[1], nl[1]);
+      } else {
+        // round to bf16 first, ReLU on the packed pairs (rounding is monotone and keeps the sign: same result)
+        unsigned p[8];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) nf[s][q] = pack2(v[8 * s + 2 * q], v[8 * s + 2 * q + 1]);
+        for (int q = 0; q < 8; ++q) p[q] = relu2(pack2(acc[2 * q], acc[2 * q + 1]));
+        if (BWD) {
+          unsigned bits = nz2(p[0]);
+#pragma unroll
+          for (int q = 1; q < 8; ++q) bits |= nz2(p[q]) << q;
+          mk16[((l * NT + t) * NCG + cg) * NTH + tid] = (unsigned short)(bits | (bits >> 8));
         }
-        if (BWD && !(a.debug & 1)) {
-          // stash position of feature 32t+16s+8(j>>2)+4h+(j&3) is p = 32t+16s+8h+j (bits 2,3 swapped; the
-          // weight-gradient kernels undo it with fperm).  Layout [row>>5][p>>3][row&31][8 bf16]: the 64 lanes
-          // of this store write one contiguous 1 KiB run (32 samples x 16 B for h = 0, then for h = 1).
-          stash_store((char*)a.stash_h + (size_t)l * a.stash_rows * (F * 2) + (so[cg] + (uint32_t)(4 * t + 2 * s) * 512u), nf[s], (a.debug >> 4) & 3);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          nf[s] = (u32x4){p[4 * s], p[4 * s + 1], p[4 * s + 2], p[4 * s + 3]};
+          if (BWD) {
+            // stash position of feature 32t+16s+8(j>>2)+4h+(j&3) is p = 32t+16s+8h+j (bits 2,3 swapped; the
+            // weight-gradient kernels undo it with fperm).  Layout [row>>5][p>>3][row&31][8 bf16]: the 64 lanes
+            // of this store write one contiguous 1 KiB run (32 samples x 16 B for h = 0, then for h = 1).
+            stash_store((char*)a.stash_h + (size_t)l * a.stash_rows * (F * 2) + (so[cg] + (uint32_t)(4 * t + 2 * s) * 512u), nf[s]);
+          }
         }
       }
     };
@@ -216,10 +255,10 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
                       b2[0], b2[1], b2[2], b2[3], b3[0], b3[1], b3[2], b3[3]};
     };
 
-    // One hidden-layer step: acc[cg] += W_tile . B over all 2*NT k-steps.  A fragments are read from the
+    // One hidden-layer tile: acc[cg] += W_tile . B over all 2*NT k-steps.  A fragments are read from the
     // slab in groups of G k-steps, two groups in flight (explicit software pipeline; sched_barrier keeps
     // hipcc from sinking the reads back next to their MFMAs), so LDS latency hides behind >= G MFMAs.
-    auto mma_step = [&](const u32x4* sl, u32x4 (*bh)[NT][2], u32x4 (*bl)[X3 ? NT : 1][2], f32x16* acc) {
+    auto mma_step = [&](const u32x4* sl, const u32x4* sll, u32x4 (*bh)[NT][2], u32x4 (*bl)[X3 ? NT : 1][2], f32x16* acc) {
       if (BWD) {      // the backward kernel is register-bound: a rolling PF-deep prefetch (PF*4 VGPRs) only
         constexpr int PF = 2;
         u32x4 ar[PF];
@@ -243,7 +282,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
 #pragma unroll
         for (int i = 0; i < G; ++i) {
           ab[b][i] = sl[(g * G + i) * 64 + lane];
-          if (X3) al[b][i] = sl[(2 * NT + g * G + i) * 64 + lane];
+          if (X3) al[b][i] = sll[(g * G + i) * 64 + lane];
         }
       };
       ldgrp(0, 0);
@@ -272,7 +311,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
     {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        if (t % TPS == 0) stepbase = step_begin();
+        if (t % TPS == 0) stepbase = (t / TPS + 1 < SPL) ? step_begin(K_L0, true) : step_begin(K_FWD, true);
         const u32x4* sl = (const u32x4*)(stepbase + (t % TPS) * SLAB0);     // [(q*2 + part)*64 + lane]
         f32x16 acc[NCG];
 #pragma unroll
@@ -302,12 +341,17 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
       f32x16 accp[NCG];
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        if (t % TPS == 0) stepbase = step_begin();
-        const u32x4* sl = (const u32x4*)(stepbase + (t % TPS) * LOADH);     // hi block [u*64 + lane], then lo block (X3)
+        if (t % TPS == 0) {
+          if (t / TPS + 1 < SPL || l < N) stepbase = step_begin(K_FWD, true);
+          else if (BWD) stepbase = step_begin(K_BWD, true);
+          else stepbase = step_begin_wrap();
+        }
+        const u32x4* sl = (const u32x4*)(stepbase + (t % TPS) * SLABT);             // hi block [u*64 + lane]
+        const u32x4* sll = (const u32x4*)(stepbase + STEPH + (t % TPS) * SLABT);    // lo block (X3)
         f32x16 acc[NCG];
 #pragma unroll
         for (int cg = 0; cg < NCG; ++cg) acc[cg] = bias_init(l, t);
-        mma_step(sl, hf, hl, acc);
+        mma_step(sl, sll, hf, hl, acc);
         if (DEFER) {
           if (t > 0) {
 #pragma unroll
@@ -367,7 +411,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
           float od = tau;
 #pragma unroll
           for (int sh = 16; sh >= 1; sh >>= 1) od += __shfl_xor(od, sh);
-          float* odb = (float*)(slot0 + 2 * (size_t)a.slot_bytes + (size_t)(N + 1) * MW * NCG * NTH * 4);   // [NW*NCG]
+          float* odb = (float*)(slot0 + 2 * (size_t)SLOT + (size_t)(N + 1) * MW * NCG * NTH * 4);   // [NW*NCG]
           if (lane == 0) odb[wave * NCG + cg] = od;
           g[cg] = sig * (1.f - sig);      // finished below, once all groups of the tile are in LDS
         } else if (sp[cg].live) g[cg] = a.dod[sp[cg].ray] * sp[cg].dt * (sig * (1.f - sig));
@@ -375,7 +419,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
     }
     if (BWD && a.mode != 0 && a.fused) {
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      const float* odb = (const float*)(slot0 + 2 * (size_t)a.slot_bytes + (size_t)(N + 1) * MW * NCG * NTH * 4);
+      const float* odb = (const float*)(slot0 + 2 * (size_t)SLOT + (size_t)(N + 1) * MW * NCG * NTH * 4);
       const int gpr = a.s_pad / GROUP;
 #pragma unroll
       for (int cg = 0; cg < NCG; ++cg) {
@@ -401,20 +445,14 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
         if (hh == 0) a.graw[m[cg]] = g[cg];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          const uint32_t bits = mk16[((N * NT + t) * NCG + cg) * NTH + tid];
+          const unsigned b32 = mask_expand(mk16[((N * NT + t) * NCG + cg) * NTH + tid]);
           const f32x4* wp = (const f32x4*)(wout_perm + (hh * NT + t) * 16);
-          float v[16];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const f32x4 w4 = wp[q];
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              v[4 * q + e] = __int_as_float(__float_as_int(w4[e] * g[cg]) & (((int)(bits << (31 - (4 * q + e)))) >> 31));
+            dz[cg][t][q >> 1][2 * (q & 1)] = pack2(w4[0] * g[cg], w4[1] * g[cg]) & halfmask(b32, 2 * q);
+            dz[cg][t][q >> 1][2 * (q & 1) + 1] = pack2(w4[2] * g[cg], w4[3] * g[cg]) & halfmask(b32, 2 * q + 1);
           }
-#pragma unroll
-          for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) dz[cg][t][s][q] = pack2(v[8 * s + 2 * q], v[8 * s + 2 * q + 1]);
         }
       }
       auto mma_step_plain = [&](const u32x4* sl, u32x4 (*bh)[NT][2], f32x16* acc) {
@@ -433,18 +471,17 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
         __builtin_amdgcn_sched_barrier(0);
       };
       auto stash_dz_tile = [&](int l, int t) {
-        if (a.debug & 1) return;
 #pragma unroll
         for (int cg = 0; cg < NCG; ++cg)
 #pragma unroll
           for (int s = 0; s < 2; ++s)
-            stash_store((char*)a.stash_dz + (size_t)l * a.stash_rows * (F * 2) + (so[cg] + (uint32_t)(4 * t + 2 * s) * 512u), dz[cg][t][s], (a.debug >> 4) & 3);
+            stash_store((char*)a.stash_dz + (size_t)l * a.stash_rows * (F * 2) + (so[cg] + (uint32_t)(4 * t + 2 * s) * 512u), dz[cg][t][s]);
       };
       for (int l = N; l >= 1; --l) {
         u32x4 dn[NCG][NT][2];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          if (t % TPS == 0) stepbase = step_begin();
+          if (t % TPS == 0) stepbase = (t / TPS + 1 < SPL || l > 1) ? step_begin(K_BWD, true) : step_begin_wrap();
           const u32x4* sl = (const u32x4*)(stepbase + (t % TPS) * SLABT);
           stash_dz_tile(l, t);                   // SPS stores per step, after the step's DMA
           f32x16 acc[NCG];
@@ -453,15 +490,11 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
           mma_step_plain(sl, dz, acc);
 #pragma unroll
           for (int cg = 0; cg < NCG; ++cg) {
-            const uint32_t bits = mk16[(((l - 1) * NT + t) * NCG + cg) * NTH + tid];
-            float v[16];
+            // dZ_{l-1} = dH_{l-1} masked by ReLU'(Z_{l-1}): round to bf16, AND the pairs with their half masks
+            const unsigned b32 = mask_expand(mk16[(((l - 1) * NT + t) * NCG + cg) * NTH + tid]);
 #pragma unroll
-            for (int j = 0; j < 16; ++j)      // sign-extended 1-bit field (v_bfe_i32) as an AND mask
-              v[j] = __int_as_float(__float_as_int(acc[cg][j]) & (((int)(bits << (31 - j))) >> 31));
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-              for (int q = 0; q < 4; ++q) dn[cg][t][s][q] = pack2(v[8 * s + 2 * q], v[8 * s + 2 * q + 1]);
+            for (int q = 0; q < 8; ++q)
+              dn[cg][t][q >> 2][q & 3] = pack2(acc[cg][2 * q], acc[cg][2 * q + 1]) & halfmask(b32, q);
           }
         }
 #pragma unroll
@@ -706,13 +739,13 @@ __global__ void __launch_bounds__(256) k_reduce_small(const ReduceArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Weight re-tiling for the bf16 kernels.  parts = 2 stores [hi | lo] slabs (X3 forward).
+// Weight re-tiling for the bf16 kernels.  parts = 2 also stores the lo parts (X3 forward) as a second stream.
 // ---------------------------------------------------------------------------------------
 struct PrepArgs16 {
   const float* params;
   char* prepared;
   int32_t F, n_hidden, k0, nk0, parts;
-  uint32_t slab0_off, slab0_bytes, fwd_off, slabh_stride, bwd_off, slabt_bytes;
+  uint32_t slab0_off, slab0_bytes, fwd_off, slabh_stride, bwd_off, slabt_bytes, lo_off;
 };
 
 __device__ __forceinline__ unsigned short bf16_rne(float x) { return (unsigned short)(pack2(x, 0.f) & 0xffffu); }
@@ -764,7 +797,7 @@ __global__ void k_prepare_bf16(const PrepArgs16 p) {
     const unsigned short hi = bf16_rne(w);
     const unsigned short val = part == 0 ? hi : bf16_rne(w - __builtin_bit_cast(float, (unsigned)hi << 16));
     unsigned short* dst = isb ? (unsigned short*)(p.prepared + p.bwd_off + slab * p.slabt_bytes)
-                              : (unsigned short*)(p.prepared + p.fwd_off + slab * p.slabh_stride);
-    dst[e0] = val;
+                              : (unsigned short*)(p.prepared + (part == 0 ? p.fwd_off : p.lo_off) + slab * p.slabt_bytes);
+    dst[e] = val;
   }
 }
