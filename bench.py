@@ -50,7 +50,8 @@ def main():
     ap.add_argument("--width", type=int, default=256)
     ap.add_argument("--cpu-rays", type=int, default=2048)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--workspace-gib", type=float, default=24.0)
+    ap.add_argument("--workspace-gib", type=float, default=128.0,
+                    help="backward stash workspace per GPU (288 GB HBM: 128 GiB holds the 512^2x128 projection in 3 ray chunks)")
     ap.add_argument("--unfused", action="store_true",
                     help="render -> mse_loss -> autograd backward (forward rendered separately) instead of the fused train step")
     args = ap.parse_args()

@@ -89,7 +89,7 @@ static PrepLayout prep_layout(const afx_ctx* c, int prec) {
     L.slabt_bytes = L.slabh_stride;
   } else {
     L.n_slab0 = NT;
-    L.slab0_bytes = rup((uint64_t)nk0_of(c) * 2 * 1024, 4096);
+    L.slab0_bytes = chain_slab0_bytes(nk0_of(c));
     L.slabt_bytes = (uint32_t)NT * 2 * 1024;
     L.slabh_stride = L.slabt_bytes;
   }
@@ -139,6 +139,22 @@ extern "C" int afx_create(const afx_model_desc* d, afx_ctx** out) {
 
 extern "C" void afx_destroy(afx_ctx* c) {
   if (!c) return;
+#ifdef AFX_STAMP
+  {
+    unsigned long long h[8][8];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps), sizeof(h)) == hipSuccess) {
+      static const char* nm[8] = {"vmcnt wait", "barrier", "request", "fwd mfma", "fwd epilogue", "bwd mfma", "bwd epilogue", "other"};
+      for (int w = 0; w < 8; ++w) {
+        unsigned long long tot = 0;
+        for (int i = 0; i < 8; ++i) tot += h[w][i];
+        if (!tot) continue;
+        fprintf(stderr, "[stamps] wave %d total %llu:", w, tot);
+        for (int i = 0; i < 8; ++i) fprintf(stderr, " %s %.1f%%", nm[i], 100.0 * h[w][i] / tot);
+        fprintf(stderr, "\n");
+      }
+    }
+  }
+#endif
   for (auto& r : c->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (auto e : c->ev_chain) if (e) (void)hipEventDestroy(e);
   for (auto e : c->ev_wgrad) if (e) (void)hipEventDestroy(e);
@@ -300,7 +316,7 @@ static int launch_chain_f(afx_ctx* c, int prec, bool bwd, const ChainArgs& a, si
 
 static int launch_chain(afx_ctx* c, int prec, bool bwd, const ChainArgs& a, hipStream_t st) {
   const int F = c->d.width, N = c->d.n_hidden;
-  size_t lds = (size_t)a.small_bytes_pad + 2 * (size_t)a.slot_bytes;
+  size_t lds = (size_t)a.small_bytes_pad + (size_t)(is_bf16(prec) ? chain_ring(bwd) : 2) * a.slot_bytes;
   const int ncg = (is_bf16(prec) && (bwd || prec == AFX_PREC_BF16)) ? 2 : 1;
   if (bwd) lds += (size_t)(N + 1) * ((c->nt + 1) / 2) * ncg * 256 * 4 + 256;   // ReLU masks + per-group optical depths
   if (lds > 160 * 1024) return fail(AFX_E_INVALID, "model needs %zu B of LDS (> 160 KiB)", lds);
@@ -479,8 +495,7 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
     graw[bI] = (float*)(ws + off); off += rup64(rows * 4, 256);
   }
   a.stash_rows = (int64_t)rows;
-  a.debug = 16;      // AFX_DEBUG: timing experiments only (bit0 skip stash stores, bits0-3 also force vmcnt(0))
-  if (const char* e = getenv("AFX_DEBUG")) a.debug = atoi(e);
+  a.debug = 0;
   a.persistent = (nbuf == 2 && !c->persistent_chain) ? 0 : 1;
   int64_t ci = 0;
   for (int64_t t0 = 0; t0 < tiles; t0 += chunk, ++ci) {

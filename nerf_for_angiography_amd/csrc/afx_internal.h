@@ -9,9 +9,12 @@ constexpr int TILE = 128;            // samples per workgroup tile (4 waves x 32
 constexpr int GROUP = 32;            // samples per wave column group; s_pad is a multiple of this
 
 // Geometry of the bf16 chain kernels' weight ring, shared by the kernels and the host (LDS size, prepared layout).
-// A step streams TPS consecutive 32-row output tiles of one layer into one LDS slot.  The backward kernel keeps its
-// ReLU masks in LDS, which leaves room for 2 tiles per step; forward-only kernels take 4.
+// A step streams TPS consecutive 32-row output tiles of one layer into one LDS slot (at least 8 KiB: one LDS-DMA
+// piece per wave of an 8-wave workgroup); a ring of RING slots is requested RING-1 steps ahead.  Forward-only
+// kernels: 2 slots of 4 tiles.  Backward kernel: its ReLU masks fill half the LDS: 2 slots of 2 tiles (a 4-slot
+// ring of one-tile steps, requested 3 steps ahead, measured 5 ms slower per 512^2x128 step: twice the barriers).
 constexpr int chain_tps(int nt, bool bwd, bool x3) { return (nt >= 4 && !bwd && !x3) ? 4 : (nt >= 2 ? 2 : 1); }
+constexpr int chain_ring(bool bwd) { return 2; }
 constexpr uint32_t chain_slab0_bytes(int nk0) { return ((uint32_t)nk0 * 2048u + 4095u) / 4096u * 4096u; }
 constexpr uint32_t chain_slot_bytes(int nt, int nk0, bool bwd, bool x3) {
   const uint32_t s0 = (uint32_t)chain_tps(nt, bwd, x3) * chain_slab0_bytes(nk0);

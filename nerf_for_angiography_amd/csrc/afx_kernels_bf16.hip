@@ -65,8 +65,10 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned relu2(unsigned p) {
   return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p), (s16x2){0, 0}));
 }
-__device__ __forceinline__ unsigned nz2(unsigned p) {
-  return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(u16x2, p), (u16x2){1, 1}));
+__device__ __forceinline__ unsigned nz2(unsigned p, unsigned one2 /* 0x00010001 */) {
+  unsigned r;      // asm: hipcc otherwise rewrites min(max(p,0),1) as compare + select + perm, 5 instructions per pair
+  asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(p), "v"(one2));
+  return r;
 }
 __device__ __forceinline__ unsigned halfmask(unsigned b, int q) {
   s16x2 v = __builtin_bit_cast(s16x2, b);
@@ -78,6 +80,15 @@ __device__ __forceinline__ unsigned halfmask(unsigned b, int q) {
 // (elements as rounded to bf16).  mask_expand() moves the two bytes to the two halves of a dword for halfmask().
 __device__ __forceinline__ unsigned mask_expand(unsigned b16) { return (b16 & 0xffu) | ((b16 & 0xff00u) << 8); }
 
+#ifdef AFX_STAMP      // diagnostic build only: per-phase cycle totals of workgroup 0's waves (s_memtime), read back by afx_destroy
+__device__ unsigned long long g_stamps[8][8];
+#define STAMP(i) do { if (BWD && NW == 8 && F == 256) { const uint64_t t_ = __builtin_amdgcn_s_memtime(); ph[i] += t_ - tlast; tlast = t_; } } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+#ifndef AFX_PP_FWD
+#define AFX_PP_FWD true
+#endif
 template <int F, bool X3, bool ENC, bool BWD, int NW>
 __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs a) {
   static_assert(!(X3 && BWD), "the backward chain runs in plain bf16");
@@ -95,19 +106,27 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
   if (a.tile0 + (int)blockIdx.x >= a.tile1) return;
 
   // A step covers TPS consecutive 32-row output tiles of one layer: one barrier and one LDS-DMA batch per step.
+#ifdef AFX_STAMP
+  uint64_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t tlast = __builtin_amdgcn_s_memtime();
+#endif
   constexpr int TPS = chain_tps(NT, BWD, X3);
+  constexpr int RING = chain_ring(BWD);               // LDS slots of the weight ring
+  constexpr int PD = RING - 1;                        // a step's slabs are requested PD steps ahead
   constexpr int SPL = NT / TPS;                       // steps per layer
   static_assert(NT % TPS == 0, "");
   // slab sizes are fixed by the template parameters (the host lays the prepared buffer out identically)
-  constexpr uint32_t SLAB0 = chain_slab0_bytes(NK0);                  // first-layer slab: NK0 x (hi,lo) KiB
+  constexpr uint32_t SLAB0 = chain_slab0_bytes(NK0);                  // first-layer slab: NK0 x (hi,lo) KiB, zero-padded
   constexpr uint32_t SLABT = NT * 2048u;                              // one hidden slab part (hi or lo)
   constexpr uint32_t STEP0 = TPS * SLAB0, STEPH = TPS * SLABT;        // bytes one step streams (X3: STEPH hi + STEPH lo)
   constexpr uint32_t SLOT = chain_slot_bytes(NT, NK0, BWD, X3);
+  constexpr int PIECES0 = STEP0 / (NW * 1024u), PIECESH = STEPH / (NW * 1024u);      // LDS-DMA instructions per wave and step
+  constexpr int SPS = 2 * NCG * TPS;                                  // stash stores per wave and step (backward kernel)
 
   char* slot0 = lds + a.small_bytes_pad;
   // The prepared buffer holds [first-layer slabs | forward hidden slabs (hi) | transposed slabs] as ONE contiguous
   // stream in the order a tile consumes it (the lo parts of the split mode are a second stream): the source of the
-  // next step is a running scalar pointer, and every step is a straight-line run of 1 KiB LDS-DMA pieces.
+  // next request is a running scalar pointer, and every request is a straight-line run of 1 KiB LDS-DMA pieces.
   const char* wnext = a.stream_fwd;
   const char* lnext = a.stream_lo;
   const uint32_t voff = (uint32_t)wave * 1024u + (uint32_t)lane * 16u;
@@ -118,60 +137,70 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
     for (uint32_t off = 0; off < BYTES; off += NW * 1024u)
       __builtin_amdgcn_global_load_lds(GPTR(src + off + voff), LPTR(dst + off + wave * 1024), 16, 0, 0);
   };
-  dma_run(wnext, slot0, std::integral_constant<uint32_t, STEP0>{});
-  wnext += STEP0;
+  // Request cursor: runs PD steps ahead of the compute, across tile boundaries, until every step of this
+  // workgroup's tiles has been requested.
+  const int steps_per_tile = SPL * (N + 1) + (BWD ? SPL * N : 0);
+  int to_issue = ((a.tile1 - a.tile0 - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x) * steps_per_tile;
+  int cpos = 0;                           // position of the next requested step inside its tile
+  uint32_t wslot = 0, rslot = 0;          // ring slot of the next request / of the next step to compute
+  auto request = [&]() {
+    char* dst = slot0 + wslot * SLOT;
+    if (cpos < SPL) {
+      dma_run(wnext, dst, std::integral_constant<uint32_t, STEP0>{});
+      wnext += STEP0;
+    } else {
+      dma_run(wnext, dst, std::integral_constant<uint32_t, STEPH>{});
+      wnext += STEPH;
+      if constexpr (X3) {                 // forward-only: every other step is a forward hidden step
+        dma_run(lnext, dst + STEPH, std::integral_constant<uint32_t, STEPH>{});
+        lnext += STEPH;
+      }
+    }
+    if (++cpos == steps_per_tile) { cpos = 0; wnext = a.stream_fwd; lnext = a.stream_lo; }
+    wslot = wslot + 1 == RING ? 0 : wslot + 1;
+    --to_issue;
+  };
+#pragma unroll
+  for (int i = 0; i < PD; ++i)
+    if (to_issue > 0) request();
 
   float* sm = (float*)lds;
   for (uint32_t i = tid * 4; i < a.small_floats; i += NTH * 4) *(f32x4*)(sm + i) = *(const f32x4*)(a.small + i);
-  unsigned short* mk16 = (unsigned short*)(slot0 + 2 * (size_t)SLOT);   // ReLU masks [((l*NT + t)*NCG + cg)*NTH + tid]
+  unsigned short* mk16 = (unsigned short*)(slot0 + RING * (size_t)SLOT);   // ReLU masks [((l*NT + t)*NCG + cg)*NTH + tid]
   const float* bias_perm = sm;
   const float* wout_perm = sm + (N + 1) * F;
   const float* aux = sm + (N + 2) * F + 4;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the first step's slabs: every later step counts (below)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the first PD steps' slabs; every later step counts (below)
   __syncthreads();
 
-  uint32_t par = 0;
-  bool has_next = false;
-  // Step protocol: wait for THIS step's slabs (LDS-DMA issued one step ago), barrier (which also retires
-  // every reader of the other slot), start the DMA of the next step's slabs, compute.  In the backward kernel
-  // each step issues at least SPS stash stores AFTER its DMA; vmcnt counts in issue order, so vmcnt(SPS)
-  // retires the DMA while the step's own stores stay in flight (a vmcnt(0) here costs a full store
-  // round-trip per step).  Raw s_barrier: __syncthreads() would re-insert vmcnt(0).
-  constexpr int SPS = 2 * NCG * TPS;
-  constexpr std::integral_constant<int, 0> K_L0{};     // the next step is a first-layer step
-  constexpr std::integral_constant<int, 1> K_FWD{};    // ... a hidden forward step
-  constexpr std::integral_constant<int, 2> K_BWD{};    // ... a transposed (input-gradient) step
-  auto step_begin = [&](auto next_c, bool doload) -> const char* {
-    constexpr int NEXT = decltype(next_c)::value;
-    if (BWD) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(SPS) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    if (doload) {
-      char* dst = slot0 + (par ^ 1u) * SLOT;
-      if constexpr (NEXT == 0) {
-        dma_run(wnext, dst, std::integral_constant<uint32_t, STEP0>{});
-        wnext += STEP0;
-      } else {
-        dma_run(wnext, dst, std::integral_constant<uint32_t, STEPH>{});
-        wnext += STEPH;
-        if constexpr (X3 && NEXT == 1) {
-          dma_run(lnext, dst + STEPH, std::integral_constant<uint32_t, STEPH>{});
-          lnext += STEPH;
-        }
-      }
+  unsigned one2 = 0x00010001u;
+  asm volatile("" : "+v"(one2));       // keep the constant in a register (VOP3P takes no literal on gfx9)
+  // Step protocol: wait for THIS step's slabs (requested PD steps ago), barrier (which also retires every reader
+  // of the slot the next request overwrites), request the slabs of the step PD ahead, compute.  vmcnt counts in
+  // issue order: behind this step's request the wave has issued the (PD-1) later requests and, in the backward
+  // kernel, at least SPS stash stores in each of the PD steps since, so vmcnt(WAITN) retires the request while
+  // the younger requests and stores stay in flight (a vmcnt(0) here would cost a store round trip per step).
+  // Raw s_barrier: __syncthreads() would re-insert vmcnt(0).
+  constexpr int WAITN = (BWD ? PD * SPS : 0) + (PD - 1) * (PIECES0 < PIECESH ? PIECES0 : PIECESH);
+  auto step_begin = [&]() -> const char* {
+    if (to_issue > 0) {
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WAITN) : "memory");
+      STAMP(0);
+      asm volatile("s_barrier" ::: "memory");
+      STAMP(1);
+      request();
+    } else {          // the last PD steps of the workgroup: nothing younger to count on
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      STAMP(1);
     }
-    const char* cur = slot0 + par * SLOT;
-    par ^= 1u;
+    STAMP(2);
+    const char* cur = slot0 + rslot * SLOT;
+    rslot = rslot + 1 == RING ? 0 : rslot + 1;
     return cur;
-  };
-  // last step of a tile: the stream restarts with the next tile's first-layer slabs
-  auto step_begin_wrap = [&]() -> const char* {
-    wnext = a.stream_fwd;
-    lnext = a.stream_lo;
-    return step_begin(K_L0, has_next);
   };
 
   for (int tile = a.tile0 + blockIdx.x; tile < a.tile1; tile += gridDim.x) {
-    has_next = tile + (int)gridDim.x < a.tile1;
+    STAMP(7);
     int32_t n[NCG];
     uint32_t m[NCG], so[NCG];           // sample index, stash row, per-lane stash byte offset (chunk 0)
     Sample sp[NCG];
@@ -231,9 +260,9 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
 #pragma unroll
         for (int q = 0; q < 8; ++q) p[q] = relu2(pack2(acc[2 * q], acc[2 * q + 1]));
         if (BWD) {
-          unsigned bits = nz2(p[0]);
+          unsigned bits = nz2(p[0], one2);
 #pragma unroll
-          for (int q = 1; q < 8; ++q) bits |= nz2(p[q]) << q;
+          for (int q = 1; q < 8; ++q) bits |= nz2(p[q], one2) << q;
           mk16[((l * NT + t) * NCG + cg) * NTH + tid] = (unsigned short)(bits | (bits >> 8));
         }
 #pragma unroll
@@ -311,7 +340,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
     {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        if (t % TPS == 0) stepbase = (t / TPS + 1 < SPL) ? step_begin(K_L0, true) : step_begin(K_FWD, true);
+        if (t % TPS == 0) stepbase = step_begin();
         const u32x4* sl = (const u32x4*)(stepbase + (t % TPS) * SLAB0);     // [(q*2 + part)*64 + lane]
         f32x16 acc[NCG];
 #pragma unroll
@@ -330,53 +359,65 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
         for (int cg = 0; cg < NCG; ++cg) epilogue(0, t, acc[cg], cg, hf[cg][t], hl[X3 ? cg : 0][X3 ? t : 0]);
       }
     }
-    // ---------------- hidden layers
-    for (int l = 1; l <= N; ++l) {
-      u32x4 nf[NCG][NT][2];
-      u32x4 nl[X3 ? NCG : 1][X3 ? NT : 1][2];
+    // ---------------- hidden layers: fragments hs -> hd
+    auto fwd_layer = [&](int l, u32x4 (*hs)[NT][2], u32x4 (*hsl)[X3 ? NT : 1][2], u32x4 (*hd)[NT][2], u32x4 (*hdl)[X3 ? NT : 1][2]) {
       // Forward-only kernels defer the epilogue of tile t-1 into step t (behind that step's MFMAs, which do
       // not depend on it) so the VALU work overlaps the matrix pipe.  The backward kernel keeps each
-      // epilogue in its own step: its stash stores are what the step's vmcnt(SPS) counts.
+      // epilogue in its own step: its stash stores are what the step's vmcnt(WAITN) counts.
       constexpr bool DEFER = !BWD;
       f32x16 accp[NCG];
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        if (t % TPS == 0) {
-          if (t / TPS + 1 < SPL || l < N) stepbase = step_begin(K_FWD, true);
-          else if (BWD) stepbase = step_begin(K_BWD, true);
-          else stepbase = step_begin_wrap();
-        }
+        if (t % TPS == 0) stepbase = step_begin();
         const u32x4* sl = (const u32x4*)(stepbase + (t % TPS) * SLABT);             // hi block [u*64 + lane]
         const u32x4* sll = (const u32x4*)(stepbase + STEPH + (t % TPS) * SLABT);    // lo block (X3)
         f32x16 acc[NCG];
 #pragma unroll
         for (int cg = 0; cg < NCG; ++cg) acc[cg] = bias_init(l, t);
-        mma_step(sl, sll, hf, hl, acc);
+        mma_step(sl, sll, hs, hsl, acc);
         if (DEFER) {
           if (t > 0) {
 #pragma unroll
             for (int cg = 0; cg < NCG; ++cg)
-              epilogue(l, t - 1, accp[cg], cg, nf[cg][t > 0 ? t - 1 : 0], nl[X3 ? cg : 0][X3 && t > 0 ? t - 1 : 0]);
+              epilogue(l, t - 1, accp[cg], cg, hd[cg][t > 0 ? t - 1 : 0], hdl[X3 ? cg : 0][X3 && t > 0 ? t - 1 : 0]);
           }
 #pragma unroll
           for (int cg = 0; cg < NCG; ++cg) accp[cg] = acc[cg];
         } else {
+          STAMP(3);
 #pragma unroll
-          for (int cg = 0; cg < NCG; ++cg) epilogue(l, t, acc[cg], cg, nf[cg][t], nl[X3 ? cg : 0][X3 ? t : 0]);
+          for (int cg = 0; cg < NCG; ++cg) epilogue(l, t, acc[cg], cg, hd[cg][t], hdl[X3 ? cg : 0][X3 ? t : 0]);
+          STAMP(4);
         }
       }
       if (DEFER) {
 #pragma unroll
         for (int cg = 0; cg < NCG; ++cg)
-          epilogue(l, NT - 1, accp[cg], cg, nf[cg][NT - 1], nl[X3 ? cg : 0][X3 ? NT - 1 : 0]);
+          epilogue(l, NT - 1, accp[cg], cg, hd[cg][NT - 1], hdl[X3 ? cg : 0][X3 ? NT - 1 : 0]);
       }
-#pragma unroll
-      for (int cg = 0; cg < NCG; ++cg)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          hf[cg][t][0] = nf[cg][t][0]; hf[cg][t][1] = nf[cg][t][1];
-          if (X3) { hl[cg][t][0] = nl[cg][t][0]; hl[cg][t][1] = nl[cg][t][1]; }
+    };
+    {
+      u32x4 nf[NCG][NT][2];
+      u32x4 nl[X3 ? NCG : 1][X3 ? NT : 1][2];
+      int l = 1;
+      // Forward-only kernels run two layers per loop trip, ping-ponging the two fragment sets (no register copies
+      // between layers); the backward kernel and the encoding variants are register-bound and spill with the doubled body.
+      if (!BWD && !ENC && AFX_PP_FWD) {
+        for (; l + 1 <= N; l += 2) {
+          fwd_layer(l, hf, hl, nf, nl);
+          fwd_layer(l + 1, nf, nl, hf, hl);
         }
+      }
+      for (; l <= N; ++l) {
+        fwd_layer(l, hf, hl, nf, nl);
+#pragma unroll
+        for (int cg = 0; cg < NCG; ++cg)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            hf[cg][t][0] = nf[cg][t][0]; hf[cg][t][1] = nf[cg][t][1];
+            if (X3) { hl[cg][t][0] = nl[cg][t][0]; hl[cg][t][1] = nl[cg][t][1]; }
+          }
+      }
     }
 
     // ---------------- output layer + Beer-Lambert / outputs
@@ -411,7 +452,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
           float od = tau;
 #pragma unroll
           for (int sh = 16; sh >= 1; sh >>= 1) od += __shfl_xor(od, sh);
-          float* odb = (float*)(slot0 + 2 * (size_t)SLOT + (size_t)(N + 1) * MW * NCG * NTH * 4);   // [NW*NCG]
+          float* odb = (float*)(slot0 + RING * (size_t)SLOT + (size_t)(N + 1) * MW * NCG * NTH * 4);   // [NW*NCG]
           if (lane == 0) odb[wave * NCG + cg] = od;
           g[cg] = sig * (1.f - sig);      // finished below, once all groups of the tile are in LDS
         } else if (sp[cg].live) g[cg] = a.dod[sp[cg].ray] * sp[cg].dt * (sig * (1.f - sig));
@@ -419,7 +460,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
     }
     if (BWD && a.mode != 0 && a.fused) {
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      const float* odb = (const float*)(slot0 + 2 * (size_t)SLOT + (size_t)(N + 1) * MW * NCG * NTH * 4);
+      const float* odb = (const float*)(slot0 + RING * (size_t)SLOT + (size_t)(N + 1) * MW * NCG * NTH * 4);
       const int gpr = a.s_pad / GROUP;
 #pragma unroll
       for (int cg = 0; cg < NCG; ++cg) {
@@ -437,6 +478,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
       asm volatile("s_barrier" ::: "memory");      // odb is rewritten by the next tile
     }
 
+    STAMP(7);
     if (BWD) {
       // ---------------- input-gradient chain, bf16 operands, fp32 accumulate
       u32x4 dz[NCG][NT][2];
@@ -481,14 +523,15 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
         u32x4 dn[NCG][NT][2];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          if (t % TPS == 0) stepbase = (t / TPS + 1 < SPL || l > 1) ? step_begin(K_BWD, true) : step_begin_wrap();
+          if (t % TPS == 0) stepbase = step_begin();
           const u32x4* sl = (const u32x4*)(stepbase + (t % TPS) * SLABT);
-          stash_dz_tile(l, t);                   // SPS stores per step, after the step's DMA
+          stash_dz_tile(l, t);                   // SPS stores per step, after the step's request
           f32x16 acc[NCG];
 #pragma unroll
           for (int cg = 0; cg < NCG; ++cg) acc[cg] = (f32x16){0.f};
           mma_step_plain(sl, dz, acc);
-#pragma unroll
+          STAMP(5);
+  #pragma unroll
           for (int cg = 0; cg < NCG; ++cg) {
             // dZ_{l-1} = dH_{l-1} masked by ReLU'(Z_{l-1}): round to bf16, AND the pairs with their half masks
             const unsigned b32 = mask_expand(mk16[(((l - 1) * NT + t) * NCG + cg) * NTH + tid]);
@@ -496,6 +539,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
             for (int q = 0; q < 8; ++q)
               dn[cg][t][q >> 2][q & 3] = pack2(acc[cg][2 * q], acc[cg][2 * q + 1]) & halfmask(b32, q);
           }
+          STAMP(6);
         }
 #pragma unroll
         for (int cg = 0; cg < NCG; ++cg)
@@ -507,6 +551,10 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef AFX_STAMP
+  if (BWD && NW == 8 && F == 256 && blockIdx.x == 0 && lane == 0)
+    for (int i = 0; i < 8; ++i) g_stamps[wave][i] += ph[i];
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
