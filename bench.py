@@ -147,26 +147,30 @@ def main():
     achieved = alg * per_launch_samples / avg_s / 1e12 if dom_ms > 0 else 0.0
     esz = 4 if args.precision == "f32" else 2
     stash_bytes = 2 * (args.layers + 1) * args.width * esz          # H_l and dZ_l written per sample by that launch
-    roofline = {"bound": "mfma", "kernel": "k_chain<bwd>: forward + Beer-Lambert + input-gradient chain + stash of H_l, dZ_l",
+    wgrad_bytes = 2 * args.layers * args.width * esz                # H_{l-1}, dZ_l of the hidden layers read back per sample
+    if args.precision != "f32" and os.environ.get("AFX_SMALL_IN_KERNEL", "1") != "0":
+        # bf16 rays mode: H_N and dZ_0 are not stashed; per 32-sample group 3 x width + 8 floats of partial sums instead
+        stash_bytes = wgrad_bytes + (3 * args.width + 8) * 4 / 32
+    roofline = {"bound": "mfma", "kernel": "k_chain<bwd>: forward + Beer-Lambert + input-gradient chain + stash of H_l, dZ_l (+ first/output-layer group sums)",
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                 "traffic": None, "launches": dom_n, "avg_launch_ms": round(avg_s * 1e3, 3),
                 "algorithmic_flop_per_sample": alg,
                 "hbm_write_GBps_algorithmic": round(stash_bytes * per_launch_samples / avg_s / 1e9, 1),
                 "kernel_ms_per_step": {k: round(v[0] / args.steps, 2) for k, v in prof.items()},
-                "wgrad_hbm_read_GBps_algorithmic": round(stash_bytes * samples_per_step / max(prof["wgrad"][0] / args.steps * 1e-3, 1e-9) / 1e9, 1),
+                "wgrad_hbm_read_GBps_algorithmic": round(wgrad_bytes * samples_per_step / max(prof["wgrad"][0] / args.steps * 1e-3, 1e-9) / 1e9, 1),
                 "step_tflops_algorithmic": round((fwd_f + dgrad_f + wgrad_f) * value / world / 1e12, 2),
                 "step_frac_of_peak": round((fwd_f + dgrad_f + wgrad_f) * value / world / 1e12 / peak, 4)}
     # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/r01_bf16_pmc.md);
     # only valid for the configuration those passes ran (the default one)
     traffic_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    default_cfg = (W, S, args.layers, args.width, fused, abs(args.workspace_gib - 24.0) < 1e-9) == (512, 128, 8, 256, True, True)
+    default_cfg = (W, S, args.layers, args.width, fused, abs(args.workspace_gib - 128.0) < 1e-9) == (512, 128, 8, 256, True, True)
     if default_cfg and os.path.exists(traffic_file):
         try:
             t = json.load(open(traffic_file)).get(args.precision)
             if t:
                 roofline["traffic"] = float(t["bytes_per_launch"])
                 roofline["traffic_source"] = t["source"]
-                roofline["algorithmic_bytes_per_launch"] = float((stash_bytes + 72) * per_launch_samples)
+                roofline["algorithmic_bytes_per_launch"] = float(stash_bytes * per_launch_samples)
         except Exception:
             pass
 

@@ -307,6 +307,7 @@ static int launch_chain_f(afx_ctx* c, int prec, bool bwd, const ChainArgs& a, si
     return enc ? launch_chain_k(c, k_chain_bf16<F, false, true, false, 4>, which, a, lds, grid, st)
                : launch_chain_k(c, k_chain_bf16<F, false, false, false, 4>, which, a, lds, grid, st);
   }
+  if (bwd && a.small_part) return launch_chain_k(c, k_chain_bf16<F, false, false, true, 8, true>, which, a, lds, grid, st, 512);
   if (bwd)
     return enc ? launch_chain_k(c, k_chain_bf16<F, false, true, true, 8>, which, a, lds, grid, st, 512)
                : launch_chain_k(c, k_chain_bf16<F, false, false, true, 8>, which, a, lds, grid, st, 512);
@@ -444,7 +445,8 @@ static int launch_wgrad16_t(afx_ctx* c, const WgradArgs& w, const ReduceArgs& rd
     ProfScope ps(c, AFX_K_WGRAD, st);
     hipLaunchKernelGGL(k_wgrad_bf16<F>, dim3(w.n_splits, N), dim3(512), lds, st, w);
   }
-  if (c->d.enc != AFX_ENC_NONE) hipLaunchKernelGGL((k_small_grads_bf16<F, true>), dim3(rd.n_small, F / 64 * 4), dim3(256), 0, st, w);
+  if (w.small_groups) hipLaunchKernelGGL(k_small_from_groups<F>, dim3(rd.n_small), dim3(F), 0, st, w);
+  else if (c->d.enc != AFX_ENC_NONE) hipLaunchKernelGGL((k_small_grads_bf16<F, true>), dim3(rd.n_small, F / 64 * 4), dim3(256), 0, st, w);
   else hipLaunchKernelGGL((k_small_grads_bf16<F, false>), dim3(rd.n_small, F / 64), dim3(256), 0, st, w);
   hipLaunchKernelGGL(k_reduce_w<F>, dim3((F * F + 255) / 256, N + 1), dim3(256), 0, st, rd);
   hipLaunchKernelGGL(k_reduce_b<F>, dim3(1, N + 2), dim3(F), 0, st, rd);
@@ -496,6 +498,9 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
   }
   a.stash_rows = (int64_t)rows;
   a.debug = 0;
+  // in-kernel small gradients: 8-wave bf16 backward kernel, rays, raw coordinates as inputs (AFX_SMALL_IN_KERNEL=0: off)
+  bool sg = b16 && a.mode == 1 && c->d.enc == AFX_ENC_NONE && c->nw_plain == 8;
+  if (const char* e = getenv("AFX_SMALL_IN_KERNEL")) sg = sg && atoi(e) != 0;
   a.persistent = (nbuf == 2 && !c->persistent_chain) ? 0 : 1;
   int64_t ci = 0;
   for (int64_t t0 = 0; t0 < tiles; t0 += chunk, ++ci) {
@@ -503,6 +508,7 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
     const int bI = nbuf == 2 ? (int)(ci & 1) : 0;
     a.tile0 = (int)t0; a.tile1 = (int)t1;
     a.stash_h = stash_h[bI]; a.stash_dz = stash_dz[bI]; a.stash_e = stash_e[bI]; a.graw = graw[bI];
+    a.small_part = sg ? (float*)((char*)stash_h[bI] + (size_t)N * rows * F * esz) : nullptr;     // H_N's stash is not written then
     if (nbuf == 2 && ci >= 2) HIPCHK(hipStreamWaitEvent(st, c->ev_wgrad[bI], 0));     // buffer bI has been consumed
     int rc = launch_chain(c, prec, true, a, st);
     if (rc) return rc;
@@ -526,7 +532,7 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
     int64_t rps = (w.rows + splits - 1) / splits;
     rps = (rps + 63) / 64 * 64;        // whole 32-/64-sample stages
     w.rows_per_split = (int)rps;
-    w.partial = partial; w.partial2 = partial2; w.partial_s = partial_s; w.debug = a.debug;
+    w.partial = partial; w.partial2 = partial2; w.partial_s = partial_s; w.debug = a.debug; w.small_groups = sg ? 1 : 0;
     ReduceArgs rd;
     rd.partial = partial; rd.partial2 = partial2; rd.n_hidden = N; rd.k0 = c->k0; rd.k0pad = k0ld; rd.n_splits = splits;
     rd.grad = grad_flat; rd.hidden_only = b16 ? 1 : 0; rd.partial_s = partial_s;

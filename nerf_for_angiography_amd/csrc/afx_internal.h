@@ -69,7 +69,9 @@ struct ChainArgs {
   const float* target;      // [R] (fused)
   float* pixel;             // [R] out (fused)
   float inv_n;              // 1 / global ray count (fused)
-  int32_t debug;            // timing experiments only: bit0 = skip stash stores (results invalid)
+  int32_t debug;            // unused
+  // in-kernel small gradients (bf16 backward, rays mode, no encoding): per 32-sample group [SW[F] S0[F] S1[F] c[3] d[3] sum_g -]
+  float* small_part;        // null: H_N, dZ_0, encoded inputs and dL/draw are stashed for k_small_grads_bf16 instead
 };
 
 struct WgradArgs {
@@ -85,6 +87,7 @@ struct WgradArgs {
   float* partial2;          // [(N+2), n_splits, F+4]
   int32_t debug;            // timing experiments only (bit5: default-policy instead of non-temporal stash loads)
   float* partial_s;         // bf16 path: [n_small, F*k0pad + 2F + 4] first-layer / output-layer partials
+  int32_t small_groups;     // 1: the chain kernel left per-group sums where H_N's stash would be (k_small_from_groups)
 };
 
 struct ReduceArgs {

@@ -89,8 +89,17 @@ __device__ unsigned long long g_stamps[8][8];
 #ifndef AFX_PP_FWD
 #define AFX_PP_FWD true
 #endif
-template <int F, bool X3, bool ENC, bool BWD, int NW>
+// SG ("small gradients in the kernel", backward, rays mode, no encoding): the first layer's and the output layer's
+// weight gradients contract over samples too, but have only 3 / 1 columns, and their operands dZ_0 and H_N were a ninth
+// of the stash traffic plus a pass of their own (k_small_grads_bf16).  A wave's 32 samples are one ray's 32-sample
+// group, on which the inputs are affine in the ray parameter, x_n = c + (t_n - t_0) d, so per group three 256-vectors
+// suffice:  SW = sum_n g_n H_N[n],  S0 = sum_n dZ_0[n],  S1 = sum_n (t_n - t_0) dZ_0[n]
+// (dW_out += SW, db_0 += S0, dW_0 += S0 c^T + S1 d^T; k_small_from_groups).  The sums run over the LANE dimension
+// of the fragments; an MFMA against a 0/1 selection matrix transposes a fragment exactly (bf16 x 1.0, fp32
+// accumulate) into the C layout - lane = feature position, 16 registers = samples - where the sum is 16 VALU FMAs.
+template <int F, bool X3, bool ENC, bool BWD, int NW, bool SG = false>
 __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs a) {
+  static_assert(!SG || (BWD && !ENC && !X3), "in-kernel small gradients: plain backward kernel without encoding");
   static_assert(!(X3 && BWD), "the backward chain runs in plain bf16");
   static_assert(!(X3 && NW != 4), "the split mode needs 512 registers per wave");
   constexpr int NT = F / 32;
@@ -113,6 +122,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
   constexpr int TPS = chain_tps(NT, BWD, X3);
   constexpr int RING = chain_ring(BWD);               // LDS slots of the weight ring
   constexpr int PD = RING - 1;                        // a step's slabs are requested PD steps ahead
+  static_assert(!SG || PD == 1, "SG marks its store-less steps for PD = 1 only");
   constexpr int SPL = NT / TPS;                       // steps per layer
   static_assert(NT % TPS == 0, "");
   // slab sizes are fixed by the template parameters (the host lays the prepared buffer out identically)
@@ -182,17 +192,18 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
   // the younger requests and stores stay in flight (a vmcnt(0) here would cost a store round trip per step).
   // Raw s_barrier: __syncthreads() would re-insert vmcnt(0).
   constexpr int WAITN = (BWD ? PD * SPS : 0) + (PD - 1) * (PIECES0 < PIECESH ? PIECES0 : PIECESH);
-  auto step_begin = [&]() -> const char* {
-    if (to_issue > 0) {
+  // `counted` = false: the previous step issued no stash stores (SG: the last forward layer's H_N is not stashed)
+  auto step_begin = [&](bool counted = true) -> const char* {
+    if (to_issue > 0 && counted) {
       asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WAITN) : "memory");
       STAMP(0);
       asm volatile("s_barrier" ::: "memory");
       STAMP(1);
-      request();
-    } else {          // the last PD steps of the workgroup: nothing younger to count on
+    } else {          // also the last PD steps of the workgroup: nothing younger to count on
       asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
       STAMP(1);
     }
+    if (to_issue > 0) request();
     STAMP(2);
     const char* cur = slot0 + rslot * SLOT;
     rslot = rslot + 1 == RING ? 0 : rslot + 1;
@@ -221,7 +232,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
           else e[j] = (hh == 0 && j < 3) ? (j == 0 ? sp[cg].px : (j == 1 ? sp[cg].py : sp[cg].pz)) : 0.f;
         }
         split_frag(e, ehi[cg][q], elo[cg][q]);
-        if (BWD) {
+        if (BWD && !SG) {
           float* ep = a.stash_e + (size_t)m[cg] * (16 * NK0) + 16 * q + 8 * hh;
           *(f32x4*)ep = (f32x4){e[0], e[1], e[2], e[3]};
           *(f32x4*)(ep + 4) = (f32x4){e[4], e[5], e[6], e[7]};
@@ -268,7 +279,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           nf[s] = (u32x4){p[4 * s], p[4 * s + 1], p[4 * s + 2], p[4 * s + 3]};
-          if (BWD) {
+          if (BWD && !(SG && l == N)) {
             // stash position of feature 32t+16s+8(j>>2)+4h+(j&3) is p = 32t+16s+8h+j (bits 2,3 swapped; the
             // weight-gradient kernels undo it with fperm).  Layout [row>>5][p>>3][row&31][8 bf16]: the 64 lanes
             // of this store write one contiguous 1 KiB run (32 samples x 16 B for h = 0, then for h = 1).
@@ -368,7 +379,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
       f32x16 accp[NCG];
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        if (t % TPS == 0) stepbase = step_begin();
+        if (t % TPS == 0) stepbase = step_begin(!(SG && l == N && t > 0));
         const u32x4* sl = (const u32x4*)(stepbase + (t % TPS) * SLABT);             // hi block [u*64 + lane]
         const u32x4* sll = (const u32x4*)(stepbase + STEPH + (t % TPS) * SLABT);    // lo block (X3)
         f32x16 acc[NCG];
@@ -479,12 +490,45 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
     }
 
     STAMP(7);
+    // SG: selection operands of the transposing MFMAs: B_s[k][j] = [j == 16 s + k]; lane (j, hh) holds k = 8 hh .. 8 hh + 7
+    u32x4 sel[2];
+    auto transpose_tile = [&](const u32x4* frag) -> f32x16 {       // D[n][j] = position 16 s + k of sample n, j = 16 s + k
+      f32x16 d = mfma_bf16(frag[0], sel[0], (f32x16){0.f});
+      return mfma_bf16(frag[1], sel[1], d);
+    };
+    if constexpr (SG) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int e = col - 16 * s2 - 8 * hh;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sel[s2][q] = (e == 2 * q) ? 0x00003f80u : ((e == 2 * q + 1) ? 0x3f800000u : 0u);
+      }
+#pragma unroll
+      for (int cg = 0; cg < NCG; ++cg) {
+        float* rec = a.small_part + (size_t)(m[cg] >> 5) * (3 * F + 8);
+        // g of the 16 sample rows this lane's accumulator registers hold: one exact f32 MFMA, D[n][j] = g_n for all j
+        const f32x16 gT = __builtin_amdgcn_mfma_f32_32x32x2f32(hh == 0 ? g[cg] : 0.f, 1.f, (f32x16){0.f}, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const f32x16 d = transpose_tile(hf[cg][t]);
+          float v = 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v = fmaf(gT[r], d[r], v);
+          v += __shfl_xor(v, 32);
+          if (hh == 0) rec[32 * t + col] = v;
+        }
+        float sg = g[cg];
+#pragma unroll
+        for (int sh = 16; sh >= 1; sh >>= 1) sg += __shfl_xor(sg, sh);
+        if (lane == 0) rec[3 * F + 6] = sg;
+      }
+    }
     if (BWD) {
       // ---------------- input-gradient chain, bf16 operands, fp32 accumulate
       u32x4 dz[NCG][NT][2];
 #pragma unroll
       for (int cg = 0; cg < NCG; ++cg) {
-        if (hh == 0) a.graw[m[cg]] = g[cg];
+        if (!SG && hh == 0) a.graw[m[cg]] = g[cg];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const unsigned b32 = mask_expand(mk16[((N * NT + t) * NCG + cg) * NTH + tid]);
@@ -523,7 +567,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
         u32x4 dn[NCG][NT][2];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          if (t % TPS == 0) stepbase = step_begin();
+          if (t % TPS == 0) stepbase = step_begin(!(SG && l == N && t == 0));
           const u32x4* sl = (const u32x4*)(stepbase + (t % TPS) * SLABT);
           stash_dz_tile(l, t);                   // SPS stores per step, after the step's request
           f32x16 acc[NCG];
@@ -546,8 +590,33 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
 #pragma unroll
           for (int t = 0; t < NT; ++t) { dz[cg][t][0] = dn[cg][t][0]; dz[cg][t][1] = dn[cg][t][1]; }
       }
+      if constexpr (SG) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t) stash_dz_tile(0, t);
+        for (int cg = 0; cg < NCG; ++cg) {
+          float* rec = a.small_part + (size_t)(m[cg] >> 5) * (3 * F + 8);
+          float tn, dx, dy, dzz;
+          ray_param(a, sp[cg], tn, dx, dy, dzz);
+          const float t0 = __shfl(tn, 0);          // the group's first sample: c = its point, t_0 = its ray parameter
+          const f32x16 dT = __builtin_amdgcn_mfma_f32_32x32x2f32(hh == 0 ? tn - t0 : 0.f, 1.f, (f32x16){0.f}, 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const f32x16 d = transpose_tile(dz[cg][t]);
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s0 += d[r]; s1 = fmaf(dT[r], d[r], s1); }
+            s0 += __shfl_xor(s0, 32);
+            s1 += __shfl_xor(s1, 32);
+            rec[F + hh * F + 32 * t + col] = hh ? s1 : s0;
+          }
+          if (lane == 0) {
+            *(f32x4*)(rec + 3 * F) = (f32x4){sp[cg].px, sp[cg].py, sp[cg].pz, dx};
+            *(f32x2*)(rec + 3 * F + 4) = (f32x2){dy, dzz};
+          }
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) stash_dz_tile(0, t);
+      }
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -753,6 +822,42 @@ __global__ void __launch_bounds__(256) k_small_grads_bf16(const WgradArgs a) {
   }
   const float vg = red32(sg);
   if (blockIdx.y == 0 && threadIdx.x == 0) P[(size_t)F * a.k0pad + 2 * F] = vg;
+}
+
+// SG mode: first-layer / output-layer partial records (the layout k_small_grads_bf16 writes) from the per-group sums
+// the chain kernel left where H_N's stash would have been.  grid = n_small blocks, block = F threads (thread p =
+// stash position, feature fperm(p)); block b sums its contiguous range of groups in order.
+template <int F>
+__global__ void __launch_bounds__(F) k_small_from_groups(const WgradArgs a) {
+  const int p = threadIdx.x, f = fperm(p);
+  const int64_t ngroups = a.rows >> 5;
+  const int64_t per = (ngroups + gridDim.x - 1) / gridDim.x;
+  int64_t g0 = (int64_t)blockIdx.x * per, g1 = g0 + per;
+  if (g1 > ngroups) g1 = ngroups;
+  constexpr int RS = 3 * F + 8;
+  const float* base = (const float*)((const char*)a.stash_h + (size_t)a.n_hidden * a.stride_rows * F * 2);
+  float aw = 0.f, a0 = 0.f, ax = 0.f, ay = 0.f, az = 0.f, sg = 0.f;
+#pragma unroll 4
+  for (int64_t g = g0; g < g1; ++g) {
+    const float* rec = base + g * RS;
+    const float sw = rec[p], s0 = rec[F + p], s1 = rec[2 * F + p];
+    const f32x4 c4 = *(const f32x4*)(rec + 3 * F);
+    const f32x4 d4 = *(const f32x4*)(rec + 3 * F + 4);      // dy, dz, sum g, -
+    aw += sw;
+    a0 += s0;
+    ax += fmaf(c4[0], s0, c4[3] * s1);
+    ay += fmaf(c4[1], s0, d4[0] * s1);
+    az += fmaf(c4[2], s0, d4[1] * s1);
+    sg += d4[2];
+  }
+  const size_t SS = (size_t)F * a.k0pad + 2 * F + 4;
+  float* P = a.partial_s + (size_t)blockIdx.x * SS;
+  P[(size_t)f * a.k0pad + 0] = ax;
+  P[(size_t)f * a.k0pad + 1] = ay;
+  P[(size_t)f * a.k0pad + 2] = az;
+  P[(size_t)F * a.k0pad + f] = a0;
+  P[(size_t)F * a.k0pad + F + f] = aw;
+  if (p == 0) P[(size_t)F * a.k0pad + 2 * F] = sg;
 }
 
 // grid = ceil(SS/64) blocks of 64 x 4 threads: 4 record groups per element (fixed-order partial sums, combined in

@@ -131,6 +131,19 @@ __device__ __forceinline__ Sample make_sample(const ChainArgs& a, int64_t n) {
   return sp;
 }
 
+// Ray parameter t of a (rays-mode) sample, p = o + t d as make_sample formed it, and the ray's direction d.
+__device__ __forceinline__ void ray_param(const ChainArgs& a, const Sample& sp, float& t, float& dx, float& dy, float& dz) {
+  float ox, oy, oz;
+  load_ray(a, sp.ray, ox, oy, oz, dx, dy, dz);
+  if (a.depth_mode == 0) {
+    const float ts = __fadd_rn(a.t_near, __fmul_rn((float)sp.s, a.t_step));
+    t = __fadd_rn(ts, __fadd_rn(ts, a.t_step)) * 0.5f;
+  } else {
+    const float* zr = a.depth_mode == 2 ? a.z + (int64_t)sp.ray * a.n_samples : a.z;
+    t = zr[sp.s];
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // Fused chain kernel.  BWD=false: inference / forward.  BWD=true: recompute the forward,
 // then the input-gradient chain, stashing H_l and dZ_l of the tile for the weight-gradient
