@@ -1,45 +1,84 @@
 #!/usr/bin/env python3
 """profiles/*.md and profiles/r01_pmc_traffic.json from the reduced rocprofv3 outputs in gpurun_out/
-(r01_stats.json, r01_fetch.json, r01_write.json - see tools/pmc_reduce.py)."""
+(r01_stats.json, r01_fetch.json, r01_write.json, r01_sq.json, r01_sq2.json - written by tools/profile_round.sh
+through tools/pmc_reduce.py)."""
 import json, os
-ROUND = "r01"
-st = json.load(open('gpurun_out/r01_stats.json'))['kernel_stats']
-fe = json.load(open('gpurun_out/r01_fetch.json'))['counters']
-wr = json.load(open('gpurun_out/r01_write.json'))['counters']
-os.makedirs('profiles', exist_ok=True)
-with open('profiles/r01_bf16_kernel_stats.md', 'w') as f:
-    f.write("# Round 1 — rocprofv3 --kernel-trace --stats of `python bench.py --no-cpu` (bf16, fused train step)\n\n")
-    f.write("MI355X, 512x512 projection x 128 samples, 8x256 CPPN, 1 warm-up + 3 timed steps (13 ray chunks per step).\n")
+
+G = "gpurun_out"
+st = json.load(open(f"{G}/r01_stats.json"))["kernel_stats"]
+fe = json.load(open(f"{G}/r01_fetch.json"))["counters"]
+wr = json.load(open(f"{G}/r01_write.json"))["counters"]
+bench = json.load(open(f"{G}/bench_default.json")) if os.path.exists(f"{G}/bench_default.json") else None
+os.makedirs("profiles", exist_ok=True)
+
+SAMPLES = 512 * 512 * 128
+F, N = 256, 8
+
+
+def find(d, key):
+    return next((k for k in d if key in k), None)
+
+
+# the stats pass runs 1 warm-up + 3 timed steps
+kc = find({r["Name"]: 1 for r in st}, "k_chain_bf16")
+calls = next(int(r["Calls"]) for r in st if r["Name"] == kc)
+chunks = calls // 4
+with open("profiles/r01_bf16_kernel_stats.md", "w") as f:
+    f.write("# Round 1 - rocprofv3 --kernel-trace --stats of `python bench.py --no-cpu` (bf16, fused train step)\n\n")
+    f.write(f"MI355X, 512x512 projection x 128 samples, 8x256 CPPN, 1 warm-up + 3 timed steps ({chunks} ray chunks per step, 128 GiB workspace).\n")
     f.write("The rocblas/at:: kernels are the synthetic phantom's ground-truth projector (before the timed region) and\n")
     f.write("PyTorch's Adam/loss; they are not on the hot path.\n\n| kernel | calls | total ms | avg ms | % |\n|---|---|---|---|---|\n")
     for r in st[:14]:
         f.write(f"| `{r['Name'][:100]}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.2f} | {float(r['AverageNs'])/1e6:.3f} | {float(r['Percentage']):.2f} |\n")
     f.write("\nbench.py times the same kernels with HIP events on the launch stream (roofline.avg_launch_ms, kernel_ms_per_step in\n"
             "profiles/r01_bench_default.json); the two agree to within the profiler's ~2-4 % slowdown.\n")
+
 tr = {}
-with open('profiles/r01_bf16_pmc.md', 'w') as f:
-    f.write("# Round 1 — HBM traffic from rocprofv3 PMC passes (bf16 fused train step)\n\n")
-    f.write("Two separate passes (`--kernel-trace --pmc FETCH_SIZE`, `--kernel-trace --pmc WRITE_SIZE`) of `python bench.py --no-cpu --steps 1 --warmup 1`\n")
-    f.write("(26 launches of each hot-path kernel = 13 ray chunks x 2 steps).  Counter unit: KiB.  Per MI355X_MICROARCH.md: on gfx950\n")
+with open("profiles/r01_bf16_pmc.md", "w") as f:
+    f.write("# Round 1 - HBM traffic and SQ counters from rocprofv3 PMC passes (bf16 fused train step)\n\n")
+    f.write("Separate passes (`--kernel-trace --pmc FETCH_SIZE`, `--kernel-trace --pmc WRITE_SIZE`, two SQ passes) of\n"
+            "`python bench.py --no-cpu --steps 1 --warmup 1` (tools/profile_round.sh).  Counter unit: KiB.  Per MI355X_MICROARCH.md: on gfx950\n")
     f.write("FETCH_SIZE reports half of the bytes of wide coalesced streaming reads (doubled below); WRITE_SIZE is exact for 16-B/lane stores.\n\n")
     f.write("| kernel | launches | FETCH_SIZE/launch (GB, x2-corrected) | WRITE_SIZE/launch (GB) | algorithmic bytes/launch (GB) |\n|---|---|---|---|---|\n")
-    chunk = 33554432 / 13
-    alg = {'k_chain_bf16': chunk * (2 * 9 * 256 * 2 + 64 + 4 + 4 * 2) / 1e9, 'k_wgrad_bf16': chunk * (2 * 8 * 256 * 2) / 1e9,
-           'k_small_grads': chunk * (2 * 256 * 2 + 64 + 4) / 1e9}
+    nl = fe[find(fe, "k_chain_bf16")]["FETCH_SIZE"]["rows"]
+    chunk = SAMPLES * 2 / nl            # 2 steps in the PMC runs
+    alg = {"k_chain_bf16": chunk * (2 * N * F * 2 + (3 * F + 8) * 4 / 32) / 1e9, "k_wgrad_bf16": chunk * (2 * N * F * 2) / 1e9,
+           "k_small_from_groups": chunk * ((3 * F + 8) * 4 / 32) / 1e9}
+    cw = wf = 0.0
     for k in fe:
-        n = fe[k]['FETCH_SIZE']['rows']
-        fg = fe[k]['FETCH_SIZE']['sum'] * 1024 * 2 / n / 1e9
-        wg = wr.get(k, {}).get('WRITE_SIZE', {'sum': 0})['sum'] * 1024 / n / 1e9
+        n = fe[k]["FETCH_SIZE"]["rows"]
+        fg = fe[k]["FETCH_SIZE"]["sum"] * 1024 * 2 / n / 1e9
+        wg = wr.get(k, {}).get("WRITE_SIZE", {"sum": 0})["sum"] * 1024 / n / 1e9
         a = next((v for kk, v in alg.items() if kk in k), None)
         f.write(f"| `{k[:70]}` | {n} | {fg:.3f} | {wg:.3f} | {'' if a is None else f'{a:.2f}'} |\n")
-        if 'k_chain_bf16' in k: tr['chain_bwd'] = (fg + wg) * 1e9; cw = wg
-        if 'k_wgrad_bf16' in k: tr['wgrad'] = (fg + wg) * 1e9; wf = fg
-    f.write(f"\nk_chain<bwd> writes the bf16 stash (H_l and dZ_l, 9.2 KB per ray-sample) exactly once: measured {cw:.1f} GB (WRITE_SIZE) vs "
-            f"{alg['k_chain_bf16']:.1f} GB algorithmic per 2.58 M-sample chunk; k_wgrad reads the 8 hidden layers' part back once "
+        if "k_chain_bf16" in k: tr["chain_bwd"] = (fg + wg) * 1e9; cw = wg
+        if "k_wgrad_bf16" in k: tr["wgrad"] = (fg + wg) * 1e9; wf = fg
+    f.write(f"\nk_chain<bwd> writes the bf16 stash (H_0..H_7 and dZ_1..dZ_8, 8.2 KB per ray-sample, plus 97 B of group sums) exactly once: "
+            f"measured {cw:.1f} GB (WRITE_SIZE) vs {alg['k_chain_bf16']:.1f} GB algorithmic per {chunk/1e6:.2f} M-sample chunk; k_wgrad reads it back once "
             f"({wf:.1f} GB after the x2 correction vs {alg['k_wgrad_bf16']:.1f} GB algorithmic). No re-reads.\n")
-json.dump({"bf16": {"bytes_per_launch": tr['chain_bwd'], "kernel": "k_chain<bwd>",
+    # SQ counters
+    for name in ("r01_sq.json", "r01_sq2.json"):
+        if not os.path.exists(f"{G}/{name}"):
+            continue
+        sq = json.load(open(f"{G}/{name}"))["counters"]
+        f.write(f"\n## SQ counters per launch ({name[:-5]}; sums over all CUs/SIMDs; SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_* count quad-cycles, "
+                "SQ_VALU_MFMA_BUSY_CYCLES cycles)\n\n")
+        ctrs = sorted({c for k in sq for c in sq[k]})
+        f.write("| kernel | " + " | ".join(ctrs) + " |\n|---|" + "---|" * len(ctrs) + "\n")
+        for k in sq:
+            if not any(t in k for t in ("k_chain_bf16", "k_wgrad_bf16", "k_small_from_groups")):
+                continue
+            f.write(f"| `{k[:60]}` | " + " | ".join(f"{sq[k][c]['sum'] / sq[k][c]['rows']:.4g}" if c in sq[k] else "" for c in ctrs) + " |\n")
+        kc2 = find(sq, "k_chain_bf16")
+        if kc2 and "SQ_VALU_MFMA_BUSY_CYCLES" in sq[kc2] and "SQ_BUSY_CYCLES" in sq[kc2]:
+            c = sq[kc2]
+            per = lambda x: c[x]["sum"] / c[x]["rows"]
+            f.write(f"\nk_chain<bwd>: SQ_VALU_MFMA_BUSY_CYCLES / launch = {per('SQ_VALU_MFMA_BUSY_CYCLES'):.4g}; "
+                    f"MFMA instructions per launch (algorithmic: samples x 2 x 8 layers x 8 tiles x 16 / 32 samples per wave) = {chunk / 32 * 2 * 8 * 8 * 16:.4g}, "
+                    f"x 32 cycles = {chunk / 32 * 2 * 8 * 8 * 16 * 32:.4g} cycles of the 1024 SIMDs.\n")
+json.dump({"bf16": {"bytes_per_launch": tr["chain_bwd"], "kernel": "k_chain<bwd>",
                     "source": "profiles/r01_bf16_pmc.md (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)",
-                    "wgrad_bytes_per_launch": tr['wgrad']}}, open('profiles/r01_pmc_traffic.json', 'w'), indent=1)
-if os.path.exists('gpurun_out/bench_default.json'):
-    open('profiles/r01_bench_default.json', 'w').write(open('gpurun_out/bench_default.json').read())
-print(open('profiles/r01_bf16_pmc.md').read()[-900:])
+                    "wgrad_bytes_per_launch": tr["wgrad"]}}, open("profiles/r01_pmc_traffic.json", "w"), indent=1)
+if bench:
+    open("profiles/r01_bench_default.json", "w").write(json.dumps(bench) + "\n")
+print(open("profiles/r01_bf16_pmc.md").read()[-2500:])
