@@ -238,8 +238,14 @@ def cpu_leg(model, args, pose, target, W, H, focal, near, far, S, device, render
                              "cores": torch.get_num_threads(), "kind": "port",
                              "sample": f"{args.cpu_rays} rays x {S} samples of the same projection, {args.layers}x{args.width} MLP, "
                                        "fp32 PyTorch-CPU oracle, fwd+bwd+Adam, best of 2 timed steps after 1 warm-up"},
-            "parity_vs_cpu_oracle": {"rays": args.cpu_rays, "weights": "the seeded initial weights (not the trained ones)", "rel_l2": rel,
-                                     "psnr_db": round(-10 * np.log10(max(mse, 1e-30)), 2),
+            "parity_vs_cpu_oracle": {"rays": args.cpu_rays, "weights": "the seeded initial weights (not the trained ones)",
+                                     # rendered projections / density grids are produced at render_precision (the training
+                                     # driver's --eval_precision default); the timed training step runs at train_precision
+                                     "render_precision": "bf16x3" if keep != "f32" else "f32",
+                                     "rel_l2": float((pix_by_prec["bf16x3" if keep != "f32" else "f32"] - pix_cpu).norm() / pix_cpu.norm()),
+                                     "psnr_db": round(-10 * np.log10(max(float(((pix_by_prec["bf16x3" if keep != "f32" else "f32"] - pix_cpu).double() ** 2).mean()), 1e-30)), 2),
+                                     "train_precision": keep, "train_precision_rel_l2": rel,
+                                     "train_precision_psnr_db": round(-10 * np.log10(max(mse, 1e-30)), 2),
                                      "rel_l2_by_precision": {k: float((v - pix_cpu).norm() / pix_cpu.norm())
                                                              for k, v in pix_by_prec.items()}}}
 

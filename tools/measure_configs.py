@@ -19,6 +19,7 @@ def model(prec="bf16"):
     m = CPPN(md).to(dev)
     with torch.no_grad():
         m.output_linear[0].weight.mul_(4.0); m.output_linear[0].bias.fill_(-5.0)
+    m.engine.max_workspace_bytes = 128 << 30      # as bench.py: 288 GB of HBM per GPU, few large ray chunks
     return m
 
 def timeit(fn, warm=1, steps=3):

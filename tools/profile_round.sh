@@ -15,5 +15,8 @@ rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT
 python3 tools/pmc_reduce.py $O/prof_sq $O/r01_sq.json > /dev/null
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE --output-format csv -d $O/prof_sq2 -- python3 bench.py --no-cpu --steps 1 --warmup 1 > $O/prof_sq2.log 2>&1
 python3 tools/pmc_reduce.py $O/prof_sq2 $O/r01_sq2.json > /dev/null
+python3 bench.py --precision f32 --steps 1 --warmup 1 > $O/bench_f32.log 2>&1 && grep "^{" $O/bench_f32.log | tail -1 > $O/bench_f32.json
+python3 bench.py --precision bf16x3 --unfused > $O/bench_x3u.log 2>&1 && grep "^{" $O/bench_x3u.log | tail -1 > $O/bench_x3_unfused.json
+python3 tools/measure_configs.py > $O/configs.log 2>&1
 rm -rf $O/prof_stats $O/prof_fetch $O/prof_write $O/prof_sq $O/prof_sq2
 ls -la $O | tail -12
