@@ -312,6 +312,9 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
             stash_store((char*)a.stash_h + (size_t)l * a.stash_rows * (F * 2) + (so[cg] + (uint32_t)(4 * t + 2 * s) * 512u), nf[s]);
           }
         }
+        // the reloaded bias is waited for HERE (it has long landed), not by an lgkmcnt(0) behind the next tile's first
+        // fragment reads, which would expose their round trip at every tile start
+        if (bt >= 0) asm volatile("" :: "v"(acc[15]));
       }
     };
 
