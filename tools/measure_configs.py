@@ -62,4 +62,24 @@ for prec in ("bf16x3", "bf16"):
         t = timeit(lambda: render_projection(m, pose, 512, 512, 13.0 * 512, 128, 1400.0, 1600.0))
     out[f"forward 512^2x128 {prec}"] = dict(ms=round(t * 1e3, 2), ray_samples_per_s=round(512 * 512 * 128 / t / 1e6, 1))
     print(prec, out[f"forward 512^2x128 {prec}"], flush=True)
+# the reference's own training iteration (run_nerf_acc.py:142-155): 75^2 = 5 625 rays x 300 samples, 4x128 MLP (and 8x256),
+# ray arrays as sample_pixel_rays returns them; fused train step + Adam per iteration
+from nerf_for_angiography_amd.engine import RenderSpec
+for layers, width in ((4, 128), (8, 256)):
+    torch.manual_seed(0)
+    md = dict(num_early_layers=layers, num_late_layers=0, num_filters=width, num_input_channels=3, num_output_channels=1,
+              num_input_channels_views=0, use_bias=True, pos_enc="none", pos_enc_basis=5, act_func="relu", fourier_sigma=5,
+              num_img=1, device=dev, precision="bf16")
+    m = CPPN(md).to(dev); opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    R, S = 5625, 300
+    o = torch.randn(R, 3, device=dev) * 3 + torch.tensor([0, 0, 1500.0], device=dev)
+    d = torch.nn.functional.normalize(torch.randn(R, 3, device=dev) * 0.03 + torch.tensor([0, 0, -1.0], device=dev), dim=-1)
+    tgt = torch.rand(R, device=dev)
+    spec = RenderSpec(n_rays=R, n_samples=S, origins=o, dirs=d, mode="acc", t_near=1400.0, t_far=1600.0)
+    def it():
+        opt.zero_grad(set_to_none=True); train_step_mse(m, spec, tgt); opt.step()
+    t = timeit(it, warm=5, steps=50)
+    out[f"reference training iteration 5625x300 {layers}x{width}"] = dict(ms_per_iter=round(t * 1e3, 3), iters_per_s=round(1 / t, 1),
+                                                                          ray_samples_per_s=round(R * S / t / 1e6, 1))
+    print(f"train-iter {layers}x{width}", out[f"reference training iteration 5625x300 {layers}x{width}"], flush=True)
 json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out", "configs.json"), "w"), indent=1)
