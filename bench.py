@@ -114,6 +114,12 @@ def main():
         opt.step()
         return loss
 
+    # the backward workspace is allocated before any timing (also with --warmup 0): a 128 GiB hipMalloc is setup, not a step
+    if fused:
+        from nerf_for_angiography_amd import _lib as afx_lib
+        full = int(model.engine.lib.afx_query(model.engine.h, afx_lib.Q_BWD_WORKSPACE_FULL, 0, W * H * ((S + 31) // 32 * 32),
+                                              afx_lib.PREC[args.precision]))
+        model.engine._workspace(min(full, model.engine.max_workspace_bytes), device)
     for i in range(args.warmup):
         step(i)
     if world > 1:
