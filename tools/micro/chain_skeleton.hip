@@ -1,0 +1,186 @@
+// Micro-benchmark (dev tool): skeletons of the backward chain kernel's inner structure, to price design alternatives
+// before building them (DESIGN.md "next levers").  No real data: B fragments are register-resident junk, the weight
+// stream is a 2 MiB L2-resident image, stash stores go to a scratch buffer.  Both variants run the same MFMA count
+// per sample (16 x v_mfma_f32_32x32x16_bf16 per 32-row tile and 32-sample column group), 2 tiles per step,
+// a 2-slot LDS ring of 32 KiB steps, one barrier per step, 2 stash stores per tile and column group.
+//   A: 8 waves x 1 column group (two waves per SIMD, <= 256 registers): epilogue after each tile's MFMAs (as k_chain<bwd>)
+//   B: 4 waves x 2 column groups (one wave per SIMD, 512 registers): every A fragment feeds two MFMAs; the epilogue of
+//      the previous tile and the LDS-DMA pieces are issued BETWEEN the MFMAs by hand (software pipeline)
+// hipcc --offload-arch=gfx950 -O3 -o /tmp/chain_skeleton tools/micro/chain_skeleton.hip && /tmp/chain_skeleton
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <type_traits>
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+#define GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define LPTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+__device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, a), __builtin_bit_cast(s16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ unsigned pack_relu(float a, float b) {
+  f32x2 v = {a, b};
+  const unsigned p = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p), (s16x2){0, 0}));
+}
+__device__ __forceinline__ void lds_read_frag(u32x4& dst, uint32_t a, int imm) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(a), "n"(imm) : "memory");
+}
+template <int K> __device__ __forceinline__ void lds_wait(u32x4& r) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(r) : "n"(K) : "memory"); }
+
+constexpr int NT = 8;            // 32-row tiles per layer (width 256)
+constexpr int SLOT = 32768;      // one step = 2 tiles x 16 KiB
+
+template <int NW, int NCG, bool STORES, bool PIPE>
+__global__ void __launch_bounds__(64 * NW, NW / 4) k_skel(const char* wts, char* stash, unsigned* sink, int steps) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  u32x4 b[NCG][NT][2];
+#pragma unroll
+  for (int cg = 0; cg < NCG; ++cg)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) b[cg][t][s] = (u32x4){0x3c003c00u + tid, 0x3c013c01u, 0x3b003b00u + t, 0x3a003a00u + s};
+  uint32_t wpos = 0;
+  const uint32_t voff = wave * 1024 + lane * 16;
+  auto piece = [&](int p, int slot) {      // piece p of this wave's share of a 32 KiB step
+    __builtin_amdgcn_global_load_lds(GPTR(wts + wpos + p * (NW * 1024) + voff), LPTR(lds + slot * SLOT + p * (NW * 1024) + wave * 1024), 16, 0, 0);
+  };
+  constexpr int PIECES = SLOT / (NW * 1024);
+#pragma unroll
+  for (int p = 0; p < PIECES; ++p) piece(p, 0);
+  wpos = (wpos + SLOT) & 0x1fffffu;
+  char* sbase = stash + ((size_t)blockIdx.x * NW + wave) * (size_t)(1 << 20) + lane * 16;
+  uint32_t soff = 0;
+  f32x16 accp[NCG];                        // PIPE: accumulators of the previous tile, drained between this tile's MFMAs
+#pragma unroll
+  for (int cg = 0; cg < NCG; ++cg) accp[cg] = (f32x16){0.f};
+  int st = 0;
+  auto step_begin = [&]() -> uint32_t {
+    const int slot = st & 1;
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(STORES ? ((PIPE && NCG == 2) ? 4 : 4 * NCG) : 0) : "memory");
+    if (!PIPE) {
+#pragma unroll
+      for (int p = 0; p < PIECES; ++p) piece(p, slot ^ 1);
+    }
+    return (uint32_t)(uintptr_t)LPTR(lds + slot * SLOT) + lane * 16;
+  };
+  uint32_t la = 0;
+  auto tile = [&](auto t_c) {
+    constexpr int t = decltype(t_c)::value, k = t & 1, tprev = (t + NT - 1) % NT;
+    if (k == 0) la = step_begin();
+    const int slot = st & 1;
+    f32x16 acc[NCG];
+#pragma unroll
+    for (int cg = 0; cg < NCG; ++cg) acc[cg] = (f32x16){0.f};
+    constexpr int PF = 4;
+    u32x4 ar[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) lds_read_frag(ar[i], la + k * 16384, i * 1024);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      if (15 - u >= PF - 1) lds_wait<PF - 1>(ar[u % PF]);
+      else if (15 - u == 2) lds_wait<2>(ar[u % PF]);
+      else if (15 - u == 1) lds_wait<1>(ar[u % PF]);
+      else lds_wait<0>(ar[u % PF]);
+      const u32x4 ah = ar[u % PF];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int cg = 0; cg < NCG; ++cg) acc[cg] = mfma(ah, b[cg][u >> 1][u & 1], acc[cg]);
+      if (u + PF < 16) lds_read_frag(ar[u % PF], la + k * 16384, (u + PF) * 1024);
+      if (PIPE) {
+        // software pipeline: slice u of the previous tile's epilogue (pair u&7 of column group u>>3; NCG = 1: slices 0..7),
+        // its stash stores in slices 8 / 12, an LDS-DMA piece of the next step every other slice of the step's first tile
+        constexpr int dummy = 0; (void)dummy;
+        const int q = u & 7, cg = (NCG == 2) ? (u >> 3) : 0;
+        if (NCG == 2 || u < 8) b[cg][tprev][q >> 2][q & 3] = pack_relu(accp[cg][2 * q], accp[cg][2 * q + 1]);
+        if (STORES && (u == 8 || u == 12)) {
+#pragma unroll
+          for (int c2 = 0; c2 < NCG; ++c2) {
+            if (NCG == 2 && ((u == 8) != (c2 == 0))) continue;       // group 0's stores in slice 8, group 1's in slice 12
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+              if (NCG == 1 && ((u == 8) != (s2 == 0))) continue;
+              __builtin_nontemporal_store(b[c2][tprev][s2], (u32x4*)(sbase + soff));
+              soff = (soff + 1024) & 0xfffffu;
+            }
+          }
+        }
+        if (k == 0 && (u & 1) == 0 && (u >> 1) < PIECES) piece(u >> 1, slot ^ 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (PIPE) {
+#pragma unroll
+      for (int cg = 0; cg < NCG; ++cg) accp[cg] = acc[cg];
+    } else {
+#pragma unroll
+      for (int cg = 0; cg < NCG; ++cg) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) b[cg][t][q >> 2][q & 3] = pack_relu(acc[cg][2 * q], acc[cg][2 * q + 1]);
+        if (STORES) {
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            __builtin_nontemporal_store(b[cg][t][s2], (u32x4*)(sbase + soff));
+            soff = (soff + 1024) & 0xfffffu;
+          }
+        }
+      }
+    }
+    if (k == 1) { wpos = (wpos + SLOT) & 0x1fffffu; ++st; }
+  };
+  for (int layer = 0; layer < steps / 4; ++layer) {      // 8 tiles = 4 steps = one layer's worth
+    tile(std::integral_constant<int, 0>{}); tile(std::integral_constant<int, 1>{});
+    tile(std::integral_constant<int, 2>{}); tile(std::integral_constant<int, 3>{});
+    tile(std::integral_constant<int, 4>{}); tile(std::integral_constant<int, 5>{});
+    tile(std::integral_constant<int, 6>{}); tile(std::integral_constant<int, 7>{});
+  }
+  unsigned x = 0;
+#pragma unroll
+  for (int cg = 0; cg < NCG; ++cg)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) x ^= b[cg][t][0][0] ^ b[cg][t][1][3];
+  x ^= __float_as_uint(accp[0][0]);
+  if (x == 0x12345678u) sink[tid] = x;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+int main() {
+  const int steps = 4096;        // 2 tiles each: 8192 tile-MFMA-loops per wave
+  char *wts, *stash; unsigned* sink;
+  CK(hipMalloc(&wts, 4 << 20)); CK(hipMemset(wts, 0x3c, 4 << 20));
+  CK(hipMalloc(&stash, (size_t)256 * 8 << 20));
+  CK(hipMalloc(&sink, 4096));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  auto run = [&](const char* name, auto kern, int nw, int ncg) -> int {
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SLOT));
+    float best = 1e30f;
+    for (int it = 0; it < 3; ++it) {
+      CK(hipEventRecord(e0));
+      hipLaunchKernelGGL(kern, dim3(256), dim3(64 * nw), 2 * SLOT, 0, wts, stash, sink, steps);
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      if (it > 0 && ms < best) best = ms;
+    }
+    const double mfmas = 256.0 * nw * ncg * steps * 2 * 16;
+    const double samples = 256.0 * nw * ncg * 32.0 * steps * 2 / (2 * 8 * NT);      // a sample = 2 x 8 layers x 8 tiles of MFMA loops
+    printf("%-44s %8.2f ms  %7.1f TFLOP/s  (%5.1f %% of 2.5 PF)  = %6.1f M samples/s of chain<bwd> MFMA work\n", name, best,
+           mfmas * 32768 / best * 1e-9, mfmas * 32768 / best * 1e-9 / 25.0, samples / best * 1e-3);
+    return 0;
+  };
+  if (run("A  8 waves x 1 group, stores", k_skel<8, 1, true, false>, 8, 1)) return 1;
+  if (run("A  8 waves x 1 group, no stores", k_skel<8, 1, false, false>, 8, 1)) return 1;
+  if (run("A' 8 waves x 1 group, pipelined, stores", k_skel<8, 1, true, true>, 8, 1)) return 1;
+  if (run("B  4 waves x 2 groups, pipelined, stores", k_skel<4, 2, true, true>, 4, 2)) return 1;
+  if (run("B  4 waves x 2 groups, pipelined, no stores", k_skel<4, 2, false, true>, 4, 2)) return 1;
+  if (run("B- 4 waves x 2 groups, not pipelined, stores", k_skel<4, 2, true, false>, 4, 2)) return 1;
+  return 0;
+}
