@@ -37,7 +37,9 @@ template <int K> __device__ __forceinline__ void lds_wait(u32x4& r) { asm volati
 constexpr int NT = 8;            // 32-row tiles per layer (width 256)
 constexpr int SLOT = 32768;      // one step = 2 tiles x 16 KiB
 
-template <int NW, int NCG, bool STORES, bool PIPE>
+// EXTRA bit 0: ReLU mask bits per tile (8 v_pk_min_u16 + shifts, one ds_write_b16, one ds_read_u16 as the backward half
+// would); bit 1: accumulators initialised from a bias row in LDS (4 broadcast ds_read_b128) instead of zero
+template <int NW, int NCG, bool STORES, bool PIPE, int EXTRA = 0>
 __global__ void __launch_bounds__(64 * NW, NW / 4) k_skel(const char* wts, char* stash, unsigned* sink, int steps) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -63,6 +65,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_skel(const char* wts, char*
   f32x16 accp[NCG];                        // PIPE: accumulators of the previous tile, drained between this tile's MFMAs
 #pragma unroll
   for (int cg = 0; cg < NCG; ++cg) accp[cg] = (f32x16){0.f};
+  unsigned one2 = 0x00010001u;
+  asm volatile("" : "+v"(one2));
   int st = 0;
   auto step_begin = [&]() -> uint32_t {
     const int slot = st & 1;
@@ -79,8 +83,16 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_skel(const char* wts, char*
     if (k == 0) la = step_begin();
     const int slot = st & 1;
     f32x16 acc[NCG];
+    unsigned short* mk = (unsigned short*)(lds + 2 * SLOT + 8192);
+    unsigned mword = 0;
 #pragma unroll
-    for (int cg = 0; cg < NCG; ++cg) acc[cg] = (f32x16){0.f};
+    for (int cg = 0; cg < NCG; ++cg) {
+      if (EXTRA & 2) {
+        const f32x16* bp = (const f32x16*)(lds + 2 * SLOT + (t * 2 + (lane >> 5)) * 64);
+        acc[cg] = *bp;
+      } else acc[cg] = (f32x16){0.f};
+      if (EXTRA & 1) mword ^= mk[(t * NCG + cg) * (64 * NW) + tid];
+    }
     constexpr int PF = 4;
     u32x4 ar[PF];
 #pragma unroll
@@ -126,6 +138,16 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_skel(const char* wts, char*
       for (int cg = 0; cg < NCG; ++cg) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) b[cg][t][q >> 2][q & 3] = pack_relu(acc[cg][2 * q], acc[cg][2 * q + 1]);
+        if (EXTRA & 1) {
+          unsigned bits = mword & 1u;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            unsigned f;
+            asm("v_pk_min_u16 %0, %1, %2" : "=v"(f) : "v"(b[cg][t][q >> 2][q & 3]), "v"(one2));
+            bits |= f << q;
+          }
+          mk[(t * NCG + cg) * (64 * NW) + tid] = (unsigned short)(bits | (bits >> 8));
+        }
         if (STORES) {
 #pragma unroll
           for (int s2 = 0; s2 < 2; ++s2) {
@@ -161,11 +183,11 @@ int main() {
   CK(hipMalloc(&sink, 4096));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   auto run = [&](const char* name, auto kern, int nw, int ncg) -> int {
-    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SLOT));
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SLOT + 16384 + 16384));
     float best = 1e30f;
     for (int it = 0; it < 3; ++it) {
       CK(hipEventRecord(e0));
-      hipLaunchKernelGGL(kern, dim3(256), dim3(64 * nw), 2 * SLOT, 0, wts, stash, sink, steps);
+      hipLaunchKernelGGL(kern, dim3(256), dim3(64 * nw), 2 * SLOT + 16384 + 16384, 0, wts, stash, sink, steps);
       CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
       if (it > 0 && ms < best) best = ms;
@@ -178,6 +200,9 @@ int main() {
   };
   if (run("A  8 waves x 1 group, stores", k_skel<8, 1, true, false>, 8, 1)) return 1;
   if (run("A  8 waves x 1 group, no stores", k_skel<8, 1, false, false>, 8, 1)) return 1;
+  if (run("A  + mask bits (LDS write + read)", k_skel<8, 1, true, false, 1>, 8, 1)) return 1;
+  if (run("A  + bias from LDS", k_skel<8, 1, true, false, 2>, 8, 1)) return 1;
+  if (run("A  + mask bits + bias", k_skel<8, 1, true, false, 3>, 8, 1)) return 1;
   if (run("A' 8 waves x 1 group, pipelined, stores", k_skel<8, 1, true, true>, 8, 1)) return 1;
   if (run("B  4 waves x 2 groups, pipelined, stores", k_skel<4, 2, true, true>, 4, 2)) return 1;
   if (run("B  4 waves x 2 groups, pipelined, no stores", k_skel<4, 2, false, true>, 4, 2)) return 1;
