@@ -41,8 +41,15 @@ enum { AFX_ENC_NONE = 0, AFX_ENC_BARF = 1, AFX_ENC_FOURIER = 2 };
  *   F32    : v_mfma_f32_32x32x2_f32, exact fp32 (strict parity mode)
  *   BF16X3 : split-bf16 (hi+lo) operands, 3 bf16 MFMAs per product, fp32
  *            accumulate: fp32-grade accuracy at 1/3 of the bf16 rate
- *   BF16   : bf16 operands, fp32 accumulate (first layer always split)     */
-enum { AFX_PREC_F32 = 0, AFX_PREC_BF16X3 = 1, AFX_PREC_BF16 = 2 };
+ *   BF16   : bf16 operands, fp32 accumulate (first layer always split)
+ *   F16    : f16 operands in the hidden layers (v_mfma_f32_32x32x16_f16: 11
+ *            significant bits at the bf16 rate), fp32 accumulate, first layer
+ *            split bf16.  Rendered pixels within ~1e-5 relative L2 of fp32.
+ *            Backward: the input-gradient chain runs normalised by dL/draw
+ *            (no loss scaling needed), the weight-gradient contraction carries
+ *            a power-of-two scale taken from the batch's largest |dL/draw|.
+ *            The training default.                                             */
+enum { AFX_PREC_F32 = 0, AFX_PREC_BF16X3 = 1, AFX_PREC_BF16 = 2, AFX_PREC_F16 = 3 };
 
 /* CPPN(model_definition) — model/CPPN.py:10-139.  Only the configuration
  * nerf/run_nerf_acc.py:168-183 builds is accelerated: ReLU, no skip block,
@@ -150,7 +157,7 @@ int afx_render_backward(afx_ctx* ctx, int prec, const void* prepared, const afx_
  * backward) without materialising anything between the steps: the backward kernel's forward recompute IS the
  * forward pass; it composites each ray in-kernel, forms dL/dpixel = 2 (pixel - target) * inv_n
  * (L = inv_n * sum_r (pixel_r - target_r)^2, inv_n = 1 / global ray count) and runs the gradient chain.
- * grad_flat += dL/dparams; args->pixel receives the rendered pixels.  bf16 precisions only; the padded
+ * grad_flat += dL/dparams; args->pixel receives the rendered pixels.  16-bit precisions (BF16X3, BF16, F16) only; the padded
  * samples per ray must divide 256 (S <= 256) so that a ray never straddles a workgroup tile. */
 int afx_train_step_mse(afx_ctx* ctx, int prec, const void* prepared, const afx_render_args* args,
                        const float* target, float inv_n, float* grad_flat, void* stream);

@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libafx.so")
 
 ENC = {"none": 0, "barf": 1, "fourier": 2}
-PREC = {"f32": 0, "bf16x3": 1, "bf16": 2}
+PREC = {"f32": 0, "bf16x3": 1, "bf16": 2, "f16": 3}
 RAYS_ARRAYS, RAYS_POSE = 0, 1
 DEPTH_UNIFORM_MID, DEPTH_SHARED_Z, DEPTH_PER_RAY_Z = 0, 1, 2
 Q_PARAM_COUNT, Q_K0, Q_PREPARED_BYTES, Q_FWD_WORKSPACE, Q_BWD_WORKSPACE_MIN, Q_BWD_WORKSPACE_FULL = range(6)
@@ -63,7 +63,7 @@ _SIGS = {
                                   C.c_void_p, C.c_void_p]),
 }
 
-_lib = None
+_libs = {}
 
 
 def exported_symbols():
@@ -71,27 +71,28 @@ def exported_symbols():
     return sorted(_SIGS)
 
 
-def load():
-    """Load libafx.so; raise loudly when it has not been built."""
-    global _lib
-    if _lib is not None:
-        return _lib
+def load(variant: str = ""):
+    """Load libafx.so (or a build variant such as the race-detector build "safe" = libafx_safe.so); raise loudly when
+    it has not been built."""
+    if variant in _libs:
+        return _libs[variant]
     # torch first: it ships its own libamdhip64.so.7; libafx.so must bind to THAT runtime (the one torch's
     # allocator and streams live in), not to a second copy pulled in through its RUNPATH.
     import torch  # noqa: F401
-    if not os.path.exists(LIB_PATH):
-        raise AfxError(f"HIP library not built: {LIB_PATH} is missing. Run `python -m nerf_for_angiography_amd.build` "
+    path = LIB_PATH if not variant else os.path.join(_HERE, "csrc", f"libafx_{variant}.so")
+    if not os.path.exists(path):
+        raise AfxError(f"HIP library not built: {path} is missing. Run `python -m nerf_for_angiography_amd.build` "
                        "(needs hipcc, --offload-arch=gfx950). There is no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
+    _libs[variant] = lib
     return lib
 
 
-def check(rc, what="afx call"):
+def check(rc, what="afx call", lib=None):
     if rc != 0:
-        msg = load().afx_last_error()
+        msg = (lib or load()).afx_last_error()
         raise AfxError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")

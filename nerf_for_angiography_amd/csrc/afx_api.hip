@@ -10,7 +10,19 @@
 #include "afx_internal.h"
 #include "afx_kernels_f32.hip"
 #include "afx_kernels_bf16.hip"
+#include "afx_inst.h"
 #include <set>
+
+// The 16-bit chain kernels are compiled in their own translation units (afx_inst_chain16.hip); -DAFX_SINGLE_TU
+// instantiates them here instead (diagnostic builds such as -DAFX_STAMP, whose device symbol must be unique).
+#ifdef AFX_SINGLE_TU
+#define AFX_CHAIN16_HERE AFX_CHAIN16_DEF
+#else
+#define AFX_CHAIN16_HERE AFX_CHAIN16_DECL
+#endif
+AFX_CHAIN16_FWD(AFX_CHAIN16_HERE, 64) AFX_CHAIN16_BWD(AFX_CHAIN16_HERE, 64)
+AFX_CHAIN16_FWD(AFX_CHAIN16_HERE, 128) AFX_CHAIN16_BWD(AFX_CHAIN16_HERE, 128)
+AFX_CHAIN16_FWD(AFX_CHAIN16_HERE, 256) AFX_CHAIN16_BWD(AFX_CHAIN16_HERE, 256)
 
 using namespace afx;
 
@@ -41,7 +53,8 @@ struct afx_ctx {
   hipStream_t side = nullptr;          // overlap mode: weight-gradient kernels run here (fork/join with events)
   hipEvent_t ev_chain[2] = {nullptr, nullptr}, ev_wgrad[2] = {nullptr, nullptr};
   int overlap, persistent_chain;
-  int nw_plain;          // waves per workgroup of the plain-bf16 chain kernels (8, or 4 via AFX_NW=4)
+  int small_in_kernel;   // first-/output-layer gradient sums inside the backward chain kernel (AFX_SMALL_IN_KERNEL=0: off)
+  int device;            // the HIP device this context was created on; every entry point checks it is current
   std::vector<ProfRec> recs;
 };
 
@@ -49,8 +62,11 @@ struct afx_ctx {
 struct ProfScope {
   afx_ctx* c; hipStream_t st; hipEvent_t a = nullptr, b = nullptr; int which;
   ProfScope(afx_ctx* c_, int which_, hipStream_t st_) : c(c_), st(st_), which(which_) {
-    if (c->profiling && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) (void)hipEventRecord(a, st);
-    else a = b = nullptr;
+    // bounded: a caller that enables profiling and never reads it back stops accumulating events after 64 Ki launches
+    if (c->profiling && c->recs.size() < 65536 && hipEventCreate(&a) == hipSuccess) {
+      if (hipEventCreate(&b) == hipSuccess) (void)hipEventRecord(a, st);
+      else { (void)hipEventDestroy(a); a = b = nullptr; }
+    } else a = b = nullptr;
   }
   ~ProfScope() {
     if (a && b) { (void)hipEventRecord(b, st); c->recs.push_back({a, b, which}); }
@@ -68,10 +84,10 @@ struct PrepLayout {
   size_t total;
 };
 
-static inline bool is_bf16(int prec) { return prec == AFX_PREC_BF16 || prec == AFX_PREC_BF16X3; }
+static inline bool is_bf16(int prec) { return prec == AFX_PREC_BF16 || prec == AFX_PREC_BF16X3 || prec == AFX_PREC_F16; }   // the 16-bit kernel family
 static inline int nk0_of(const afx_ctx* c) { return c->d.enc == AFX_ENC_NONE ? 1 : 4; }
 // samples per workgroup tile of the forward / backward chain kernel
-static inline int fwd_tile(int prec) { return prec == AFX_PREC_BF16 ? 256 : 128; }
+static inline int fwd_tile(int prec) { return (prec == AFX_PREC_BF16 || prec == AFX_PREC_F16) ? 256 : 128; }
 static inline int bwd_tile(int prec) { return prec == AFX_PREC_F32 ? 128 : 256; }
 
 static PrepLayout prep_layout(const afx_ctx* c, int prec) {
@@ -122,17 +138,20 @@ extern "C" int afx_create(const afx_model_desc* d, afx_ctx** out) {
   if (c->k0pad > d->width) { delete c; return fail(AFX_E_INVALID, "afx_create: encoded width %d exceeds layer width", c->k0pad); }
   const int64_t F = d->width;
   c->n_params = F * c->k0 + F + (int64_t)d->n_hidden * (F * F + F) + F + 1;
-  int dev = 0;
+  int dev = -1;
   hipDeviceProp_t prop;
   c->n_cu = 256;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
     c->n_cu = prop.multiProcessorCount;
+  else dev = -1;         // no GPU: queries and validation still work, launches fail with a HIP error
+  c->device = dev;
   c->profiling = false;
-  c->nw_plain = 8;
   c->overlap = 0; c->persistent_chain = 0;     // AFX_OVERLAP=1: chain(i+1) || wgrad(i) on two streams (+2.6 % on the 512^2x128 step; per-kernel times inflate)
+  c->small_in_kernel = 1;
+  // environment knobs are read ONCE, here (never on the launch path)
   if (const char* e = getenv("AFX_OVERLAP")) c->overlap = atoi(e);
   if (const char* e = getenv("AFX_PERSISTENT")) c->persistent_chain = atoi(e);
-  if (const char* e = getenv("AFX_NW")) { if (atoi(e) == 4) c->nw_plain = 4; }
+  if (const char* e = getenv("AFX_SMALL_IN_KERNEL")) c->small_in_kernel = atoi(e) != 0;
   *out = c;
   return AFX_OK;
 }
@@ -172,16 +191,18 @@ extern "C" int afx_profile_read(afx_ctx* c, int which, double* ms_total, int64_t
   if (!c || !ms_total || !launches) return fail(AFX_E_INVALID, "afx_profile_read: null argument");
   double tot = 0.0;
   int64_t n = 0;
-  std::vector<ProfRec> keep;
-  for (auto& r : c->recs) {
-    if (r.which != which) { keep.push_back(r); continue; }
-    HIPCHK(hipEventSynchronize(r.b));
+  std::vector<ProfRec> keep, mine;
+  for (auto& r : c->recs) (r.which == which ? mine : keep).push_back(r);
+  c->recs.swap(keep);          // from here on every record of `which` is owned (and destroyed exactly once) by this call
+  hipError_t err = hipSuccess;
+  for (auto& r : mine) {
     float ms = 0.f;
-    HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
-    tot += ms; ++n;
+    if (err == hipSuccess) err = hipEventSynchronize(r.b);
+    if (err == hipSuccess) err = hipEventElapsedTime(&ms, r.a, r.b);
+    if (err == hipSuccess) { tot += ms; ++n; }
     (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
   }
-  c->recs.swap(keep);
+  if (err != hipSuccess) return fail(AFX_E_HIP, "afx_profile_read: %s (%d)", hipGetErrorString(err), (int)err);
   *ms_total = tot; *launches = n;
   return AFX_OK;
 }
@@ -216,6 +237,7 @@ static BwdLayout bwd_layout(const afx_ctx* c, int prec, int64_t n_rays) {
   fixed += rup64((N + 1) * (size_t)kSplits * F * F * 4, 256);     // partial
   fixed += rup64((N + 2) * (size_t)kSplits * (F + 4) * 4, 256);   // partial2
   if (prec != AFX_PREC_F32) fixed += rup64((size_t)kSmallBlocks * (F * 16 * nk0_of(c) + 2 * F + 4) * 4, 256);   // partial_s
+  fixed += 256;                                                     // gmax words (f16 mode), one per stash buffer
   B.fixed_bytes = fixed;
   if (prec == AFX_PREC_F32) B.per_tile_bytes = (size_t)128 * 4 * (2 * (N + 1) * F + c->k0pad + 1);
   else B.per_tile_bytes = (size_t)256 * (2 * (N + 1) * F * 2 + 4 * 16 * nk0_of(c) + 4);
@@ -246,8 +268,17 @@ extern "C" int64_t afx_query(const afx_ctx* c, int what, int64_t a0, int64_t a1,
   return -1;
 }
 
+// Launches go to the stream the caller passes, which belongs to the caller's CURRENT device: the context's CU count,
+// function attributes and workspace sizing are those of the device it was created on, so the two must agree.
+static int check_dev(const afx_ctx* c, const char* who) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) return fail(AFX_E_HIP, "%s: no HIP device", who);
+  if (dev != c->device) return fail(AFX_E_INVALID, "%s: context belongs to device %d but device %d is current", who, c->device, dev);
+  return AFX_OK;
+}
+
 static int check_prec(int prec, const char* who) {
-  if (prec != AFX_PREC_F32 && prec != AFX_PREC_BF16X3 && prec != AFX_PREC_BF16) return fail(AFX_E_INVALID, "%s: unknown precision %d", who, prec);
+  if (prec != AFX_PREC_F32 && prec != AFX_PREC_BF16X3 && prec != AFX_PREC_BF16 && prec != AFX_PREC_F16) return fail(AFX_E_INVALID, "%s: unknown precision %d", who, prec);
   return AFX_OK;
 }
 
@@ -258,6 +289,7 @@ extern "C" int afx_prepare_weights(afx_ctx* c, int prec, const float* params, co
   if (c->d.enc != AFX_ENC_NONE && !enc_aux) return fail(AFX_E_INVALID, "afx_prepare_weights: enc_aux required for this encoding");
   const PrepLayout L = prep_layout(c, prec);
   if (prepared_bytes < L.total) return fail(AFX_E_WORKSPACE, "afx_prepare_weights: prepared buffer %zu < %zu bytes", prepared_bytes, L.total);
+  if (int rc = check_dev(c, "afx_prepare_weights")) return rc;
   PrepArgs p;
   p.params = params; p.enc_aux = enc_aux; p.prepared = (char*)prepared;
   p.F = c->d.width; p.n_hidden = c->d.n_hidden; p.k0 = c->k0; p.nq = c->nq; p.enc = c->d.enc; p.n_freq = c->d.n_freq;
@@ -270,7 +302,7 @@ extern "C" int afx_prepare_weights(afx_ctx* c, int prec, const float* params, co
     q.params = params; q.prepared = (char*)prepared;
     q.F = c->d.width; q.n_hidden = c->d.n_hidden; q.k0 = c->k0; q.nk0 = nk0_of(c); q.parts = prec == AFX_PREC_BF16X3 ? 2 : 1;
     q.slab0_off = L.slab0_off; q.slab0_bytes = L.slab0_bytes; q.fwd_off = L.fwd_off; q.slabh_stride = L.slabh_stride;
-    q.bwd_off = L.bwd_off; q.slabt_bytes = L.slabt_bytes; q.lo_off = L.lo_off;
+    q.bwd_off = L.bwd_off; q.slabt_bytes = L.slabt_bytes; q.lo_off = L.lo_off; q.h16 = prec == AFX_PREC_F16 ? 1 : 0;
     hipLaunchKernelGGL(k_prepare_bf16, dim3(512), dim3(256), 0, (hipStream_t)stream, q);
   }
   HIPCHK(hipGetLastError());
@@ -300,12 +332,13 @@ static int launch_chain_f(afx_ctx* c, int prec, bool bwd, const ChainArgs& a, si
   if (prec == AFX_PREC_BF16X3 && !bwd)
     return enc ? launch_chain_k(c, k_chain_bf16<F, true, true, false, 4>, which, a, lds, grid, st)
                : launch_chain_k(c, k_chain_bf16<F, true, false, false, 4>, which, a, lds, grid, st);
-  if (c->nw_plain == 4) {
+  if (prec == AFX_PREC_F16) {
+    if (bwd && a.small_part) return launch_chain_k(c, k_chain_bf16<F, false, false, true, 8, true, true>, which, a, lds, grid, st, 512);
     if (bwd)
-      return enc ? launch_chain_k(c, k_chain_bf16<F, false, true, true, 4>, which, a, lds, grid, st)
-                 : launch_chain_k(c, k_chain_bf16<F, false, false, true, 4>, which, a, lds, grid, st);
-    return enc ? launch_chain_k(c, k_chain_bf16<F, false, true, false, 4>, which, a, lds, grid, st)
-               : launch_chain_k(c, k_chain_bf16<F, false, false, false, 4>, which, a, lds, grid, st);
+      return enc ? launch_chain_k(c, k_chain_bf16<F, false, true, true, 8, false, true>, which, a, lds, grid, st, 512)
+                 : launch_chain_k(c, k_chain_bf16<F, false, false, true, 8, false, true>, which, a, lds, grid, st, 512);
+    return enc ? launch_chain_k(c, k_chain_bf16<F, false, true, false, 8, false, true>, which, a, lds, grid, st, 512)
+               : launch_chain_k(c, k_chain_bf16<F, false, false, false, 8, false, true>, which, a, lds, grid, st, 512);
   }
   if (bwd && a.small_part) return launch_chain_k(c, k_chain_bf16<F, false, false, true, 8, true>, which, a, lds, grid, st, 512);
   if (bwd)
@@ -318,11 +351,12 @@ static int launch_chain_f(afx_ctx* c, int prec, bool bwd, const ChainArgs& a, si
 static int launch_chain(afx_ctx* c, int prec, bool bwd, const ChainArgs& a, hipStream_t st) {
   const int F = c->d.width, N = c->d.n_hidden;
   size_t lds = (size_t)a.small_bytes_pad + (size_t)(is_bf16(prec) ? chain_ring(bwd) : 2) * a.slot_bytes;
-  const int ncg = (is_bf16(prec) && (bwd || prec == AFX_PREC_BF16)) ? 2 : 1;
+  const int ncg = (is_bf16(prec) && (bwd || prec == AFX_PREC_BF16 || prec == AFX_PREC_F16)) ? 2 : 1;
   if (bwd) lds += (size_t)(N + 1) * ((c->nt + 1) / 2) * ncg * 256 * 4 + 256;   // ReLU masks + per-group optical depths
   if (lds > 160 * 1024) return fail(AFX_E_INVALID, "model needs %zu B of LDS (> 160 KiB)", lds);
   const int tiles = a.tile1 - a.tile0;
   if (tiles <= 0) return AFX_OK;
+  if (int rc = check_dev(c, "afx chain launch")) return rc;
   const int grid = (tiles < c->n_cu || !a.persistent) ? tiles : c->n_cu;    // persistent: one workgroup per CU loops over tiles
   if (F == 64) return launch_chain_f<64>(c, prec, bwd, a, lds, grid, st);
   if (F == 128) return launch_chain_f<128>(c, prec, bwd, a, lds, grid, st);
@@ -434,20 +468,21 @@ static int launch_wgrad_t(afx_ctx* c, const WgradArgs& w, const ReduceArgs& rd, 
   return AFX_OK;
 }
 
-template <int F>
+template <int F, bool H16>
 static int launch_wgrad16_t(afx_ctx* c, const WgradArgs& w, const ReduceArgs& rd, int N, hipStream_t st) {
   {
-    const size_t lds = (size_t)4 * (F / 8) * (64 * 16 + 64);   // 2 stages x (dZ + H image of 64 samples, padded chunk columns)
-    if (!c->attr_done.count((const void*)k_wgrad_bf16<F>)) {
-      HIPCHK(hipFuncSetAttribute((const void*)k_wgrad_bf16<F>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      c->attr_done.insert((const void*)k_wgrad_bf16<F>);
+    // 2 stages x (dZ + H image of 64 samples, padded chunk columns) (+ f16 mode: 2 stages of scaled dL/draw)
+    const size_t lds = (size_t)4 * (F / 8) * (64 * 16 + 64) + (H16 ? 2 * (64 * 2 + 64 * 4) : 0);
+    if (!c->attr_done.count((const void*)k_wgrad_bf16<F, H16>)) {
+      HIPCHK(hipFuncSetAttribute((const void*)k_wgrad_bf16<F, H16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      c->attr_done.insert((const void*)k_wgrad_bf16<F, H16>);
     }
     ProfScope ps(c, AFX_K_WGRAD, st);
-    hipLaunchKernelGGL(k_wgrad_bf16<F>, dim3(w.n_splits, N), dim3(512), lds, st, w);
+    hipLaunchKernelGGL((k_wgrad_bf16<F, H16>), dim3(w.n_splits, N), dim3(512), lds, st, w);
   }
   if (w.small_groups) hipLaunchKernelGGL(k_small_from_groups<F>, dim3(rd.n_small), dim3(F), 0, st, w);
-  else if (c->d.enc != AFX_ENC_NONE) hipLaunchKernelGGL((k_small_grads_bf16<F, true>), dim3(rd.n_small, F / 64 * 4), dim3(256), 0, st, w);
-  else hipLaunchKernelGGL((k_small_grads_bf16<F, false>), dim3(rd.n_small, F / 64), dim3(256), 0, st, w);
+  else if (c->d.enc != AFX_ENC_NONE) hipLaunchKernelGGL((k_small_grads_bf16<F, true, H16>), dim3(rd.n_small, F / 64 * 4), dim3(256), 0, st, w);
+  else hipLaunchKernelGGL((k_small_grads_bf16<F, false, H16>), dim3(rd.n_small, F / 64), dim3(256), 0, st, w);
   hipLaunchKernelGGL(k_reduce_w<F>, dim3((F * F + 255) / 256, N + 1), dim3(256), 0, st, rd);
   hipLaunchKernelGGL(k_reduce_b<F>, dim3(1, N + 2), dim3(F), 0, st, rd);
   hipLaunchKernelGGL(k_reduce_small<F>, dim3((unsigned)((F * rd.k0pad + 2 * F + 1 + 63) / 64)), dim3(64, 4), 0, st, rd);
@@ -488,6 +523,8 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
   float* partial2 = (float*)(ws + off); off += rup64((size_t)(N + 2) * kSplits * (F + 4) * 4, 256);
   float* partial_s = (float*)(ws + off);
   if (b16) off += rup64((size_t)kSmallBlocks * (F * k0ld + 2 * F + 4) * 4, 256);
+  uint32_t* gmax_words = (uint32_t*)(ws + off); off += 256;
+  const bool h16 = prec == AFX_PREC_F16;
   const size_t rows = (size_t)chunk * TILE;
   float *stash_h[2], *stash_dz[2], *stash_e[2], *graw[2];
   for (int bI = 0; bI < nbuf; ++bI) {
@@ -499,8 +536,7 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
   a.stash_rows = (int64_t)rows;
   a.debug = 0;
   // in-kernel small gradients: 8-wave bf16 backward kernel, rays, raw coordinates as inputs (AFX_SMALL_IN_KERNEL=0: off)
-  bool sg = b16 && a.mode == 1 && c->d.enc == AFX_ENC_NONE && c->nw_plain == 8;
-  if (const char* e = getenv("AFX_SMALL_IN_KERNEL")) sg = sg && atoi(e) != 0;
+  const bool sg = b16 && a.mode == 1 && c->d.enc == AFX_ENC_NONE && c->small_in_kernel;
   a.persistent = (nbuf == 2 && !c->persistent_chain) ? 0 : 1;
   int64_t ci = 0;
   for (int64_t t0 = 0; t0 < tiles; t0 += chunk, ++ci) {
@@ -510,6 +546,8 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
     a.stash_h = stash_h[bI]; a.stash_dz = stash_dz[bI]; a.stash_e = stash_e[bI]; a.graw = graw[bI];
     a.small_part = sg ? (float*)((char*)stash_h[bI] + (size_t)N * rows * F * esz) : nullptr;     // H_N's stash is not written then
     if (nbuf == 2 && ci >= 2) HIPCHK(hipStreamWaitEvent(st, c->ev_wgrad[bI], 0));     // buffer bI has been consumed
+    a.gmax = h16 ? gmax_words + 16 * bI : nullptr;
+    if (h16) HIPCHK(hipMemsetAsync(a.gmax, 0, 4, st));
     int rc = launch_chain(c, prec, true, a, st);
     if (rc) return rc;
     hipStream_t ws_st = st;
@@ -533,13 +571,15 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
     rps = (rps + 63) / 64 * 64;        // whole 32-/64-sample stages
     w.rows_per_split = (int)rps;
     w.partial = partial; w.partial2 = partial2; w.partial_s = partial_s; w.debug = a.debug; w.small_groups = sg ? 1 : 0;
+    w.gmax = a.gmax;
     ReduceArgs rd;
     rd.partial = partial; rd.partial2 = partial2; rd.n_hidden = N; rd.k0 = c->k0; rd.k0pad = k0ld; rd.n_splits = splits;
     rd.grad = grad_flat; rd.hidden_only = b16 ? 1 : 0; rd.partial_s = partial_s;
     rd.n_small = kSmallBlocks;      // records; every record is written (possibly with zero rows)
-    if (F == 64) rc = b16 ? launch_wgrad16_t<64>(c, w, rd, N, ws_st) : launch_wgrad_t<64>(c, w, rd, N, ws_st);
-    else if (F == 128) rc = b16 ? launch_wgrad16_t<128>(c, w, rd, N, ws_st) : launch_wgrad_t<128>(c, w, rd, N, ws_st);
-    else rc = b16 ? launch_wgrad16_t<256>(c, w, rd, N, ws_st) : launch_wgrad_t<256>(c, w, rd, N, ws_st);
+    rd.gmax = a.gmax;
+    if (!b16) rc = F == 64 ? launch_wgrad_t<64>(c, w, rd, N, ws_st) : (F == 128 ? launch_wgrad_t<128>(c, w, rd, N, ws_st) : launch_wgrad_t<256>(c, w, rd, N, ws_st));
+    else if (h16) rc = F == 64 ? launch_wgrad16_t<64, true>(c, w, rd, N, ws_st) : (F == 128 ? launch_wgrad16_t<128, true>(c, w, rd, N, ws_st) : launch_wgrad16_t<256, true>(c, w, rd, N, ws_st));
+    else rc = F == 64 ? launch_wgrad16_t<64, false>(c, w, rd, N, ws_st) : (F == 128 ? launch_wgrad16_t<128, false>(c, w, rd, N, ws_st) : launch_wgrad16_t<256, false>(c, w, rd, N, ws_st));
     if (rc) return rc;
     if (nbuf == 2) HIPCHK(hipEventRecord(c->ev_wgrad[bI], c->side));
   }

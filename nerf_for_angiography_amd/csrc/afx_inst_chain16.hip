@@ -1,0 +1,11 @@
+// afx_inst_chain16.hip — explicit instantiations of the 16-bit chain kernels for ONE width and direction
+// (-DAFX_INST_F=64|128|256 -DAFX_INST_BWD=0|1): the library is built from several translation units in parallel.
+#define AFX_TEMPLATES_ONLY
+#include "afx_kernels_f32.hip"
+#include "afx_kernels_bf16.hip"
+#include "afx_inst.h"
+#if AFX_INST_BWD
+AFX_CHAIN16_BWD(AFX_CHAIN16_DEF, AFX_INST_F)
+#else
+AFX_CHAIN16_FWD(AFX_CHAIN16_DEF, AFX_INST_F)
+#endif

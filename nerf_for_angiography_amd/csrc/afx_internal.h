@@ -72,6 +72,7 @@ struct ChainArgs {
   int32_t debug;            // unused
   // in-kernel small gradients (bf16 backward, rays mode, no encoding): per 32-sample group [SW[F] S0[F] S1[F] c[3] d[3] sum_g -]
   float* small_part;        // null: H_N, dZ_0, encoded inputs and dL/draw are stashed for k_small_grads_bf16 instead
+  uint32_t* gmax;           // f16 mode: bit pattern of max |dL/draw| over the chunk (integer atomicMax; zeroed per chunk)
 };
 
 struct WgradArgs {
@@ -88,6 +89,7 @@ struct WgradArgs {
   int32_t debug;            // timing experiments only (bit5: default-policy instead of non-temporal stash loads)
   float* partial_s;         // bf16 path: [n_small, F*k0pad + 2F + 4] first-layer / output-layer partials
   int32_t small_groups;     // 1: the chain kernel left per-group sums where H_N's stash would be (k_small_from_groups)
+  const uint32_t* gmax;     // f16 mode: the chunk's max |dL/draw| (scale of the contraction, wgrad_scale_exp)
 };
 
 struct ReduceArgs {
@@ -98,6 +100,7 @@ struct ReduceArgs {
   int32_t n_small;
   const float* partial_s;
   float* grad;              // flat parameter gradient, accumulated into
+  const uint32_t* gmax;     // f16 mode: hidden-layer partials carry the factor 2^-e (wgrad_scale_exp); null otherwise
 };
 
 }  // namespace afx

@@ -10,7 +10,12 @@
 //                A fragment read from LDS feeds two MFMAs.
 //   X3 = true  : split-bf16: x = hi + lo (both bf16), products hi*hi + hi*lo + lo*hi, fp32 accumulate:
 //                ~2^-17 relative error per product (fp32-grade) for 3 MFMAs; 32 columns per wave.
-//   The first layer (raw world coordinates, +-100) is always split; the output layer (width -> 1) and
+//   H16 = true : the hidden layers run on v_mfma_f32_32x32x16_f16 (f16 operands, 11 significant bits instead of 8,
+//                same rate): forward pixel error vs the fp32 oracle ~1e-5 instead of ~2e-4 relative L2.  The backward
+//                kernel then runs the input-gradient chain NORMALISED, J_l = dZ_l / g (g = dL/draw of the sample): J does
+//                not inherit g's 40-binade range, so f16 needs no loss scaling; g is stored per sample and re-applied by
+//                the weight-gradient kernel (and by the in-kernel first-/output-layer sums).
+//   The first layer (raw world coordinates, +-100) is always split bf16; the output layer (width -> 1) and
 //   the compositing run in fp32 on the VALU.
 #include <hip/hip_runtime.h>
 #include <type_traits>
@@ -21,6 +26,8 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ unsigned pack2(float a, float b) {       // -> v_cvt_pk_bf16_f32 (RNE)
@@ -32,6 +39,20 @@ __device__ __forceinline__ float bf_hi(unsigned p) { return __builtin_bit_cast(f
 __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, a), __builtin_bit_cast(s16x8, b), c, 0, 0, 0);
 }
+// f16 forms (H16 kernels): v_cvt_pk_f16_f32 (RNE) and v_mfma_f32_32x32x16_f16
+__device__ __forceinline__ unsigned pack2h(float a, float b) {
+  f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_t));
+}
+__device__ __forceinline__ float h_lo(unsigned p) { return (float)__builtin_bit_cast(f16x2_t, p)[0]; }
+__device__ __forceinline__ float h_hi(unsigned p) { return (float)__builtin_bit_cast(f16x2_t, p)[1]; }
+__device__ __forceinline__ f32x16 mfma_f16(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+template <bool H16> __device__ __forceinline__ unsigned pack2t(float a, float b) { return H16 ? pack2h(a, b) : pack2(a, b); }
+template <bool H16> __device__ __forceinline__ f32x16 mfma_t(u32x4 a, u32x4 b, f32x16 c) { return H16 ? mfma_f16(a, b, c) : mfma_bf16(a, b, c); }
+template <bool H16> __device__ __forceinline__ float lo_t(unsigned p) { return H16 ? h_lo(p) : bf_lo(p); }
+template <bool H16> __device__ __forceinline__ float hi_t(unsigned p) { return H16 ? h_hi(p) : bf_hi(p); }
 
 // 8 fp32 values -> one hi fragment (and the residual lo fragment)
 __device__ __forceinline__ void split_frag(const float* v, u32x4& hi, u32x4& lo) {
@@ -95,8 +116,15 @@ __device__ unsigned long long g_stamps[8][8];
 __device__ __forceinline__ void lds_read_frag(u32x4& dst, uint32_t lds_addr, int imm) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "n"(imm) : "memory");
 }
+// -DAFX_SAFE_WAITS (the race-detector build, libafx_safe.so): every counted wait of the chain kernels becomes a full
+// one - lgkmcnt(0) before each MFMA, vmcnt(0) + barrier at every step.  tests/ assert the production library is
+// bit-identical to it at full size: an under-counted wait cannot hide behind run-to-run determinism.
 template <int K> __device__ __forceinline__ void lds_wait_frag(u32x4& r) {
+#ifdef AFX_SAFE_WAITS
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r) :: "memory");
+#else
   asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(r) : "n"(K) : "memory");
+#endif
 }
 #ifndef AFX_PF_FWD
 #define AFX_PF_FWD 4
@@ -113,9 +141,10 @@ template <int K> __device__ __forceinline__ void lds_wait_frag(u32x4& r) {
 // (dW_out += SW, db_0 += S0, dW_0 += S0 c^T + S1 d^T; k_small_from_groups).  The sums run over the LANE dimension
 // of the fragments; an MFMA against a 0/1 selection matrix transposes a fragment exactly (bf16 x 1.0, fp32
 // accumulate) into the C layout - lane = feature position, 16 registers = samples - where the sum is 16 VALU FMAs.
-template <int F, bool X3, bool ENC, bool BWD, int NW, bool SG = false>
+template <int F, bool X3, bool ENC, bool BWD, int NW, bool SG = false, bool H16 = false>
 __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs a) {
   static_assert(!SG || (BWD && !ENC && !X3), "in-kernel small gradients: plain backward kernel without encoding");
+  static_assert(!(H16 && (X3 || NW != 8)), "f16 hidden layers: 8-wave kernels only");
   static_assert(!(X3 && BWD), "the backward chain runs in plain bf16");
   static_assert(!(X3 && NW != 4), "the split mode needs 512 registers per wave");
   constexpr int NT = F / 32;
@@ -210,6 +239,9 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
   constexpr int WAITN = (BWD ? PD * SPS : 0) + (PD - 1) * (PIECES0 < PIECESH ? PIECES0 : PIECESH);
   // `counted` = false: the previous step issued no stash stores (SG: the last forward layer's H_N is not stashed)
   auto step_begin = [&](bool counted = true) -> const char* {
+#ifdef AFX_SAFE_WAITS
+    counted = false;
+#endif
     if (to_issue > 0 && counted) {
       asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WAITN) : "memory");
       STAMP(0);
@@ -294,7 +326,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
         // round to bf16 first, ReLU on the packed pairs (rounding is monotone and keeps the sign: same result)
         unsigned p[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) p[q] = relu2(pack2(acc[2 * q], acc[2 * q + 1]));
+        for (int q = 0; q < 8; ++q) p[q] = relu2(pack2t<H16>(acc[2 * q], acc[2 * q + 1]));
         if (bt >= 0) acc = bias_init(bl, bt);
         if (BWD) {
           unsigned bits = nz2(p[0], one2);
@@ -337,7 +369,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
         const u32x4 ah = ar[u % PF];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int cg = 0; cg < NCG; ++cg) acc[cg] = mfma_bf16(ah, bh[cg][u >> 1][u & 1], acc[cg]);
+        for (int cg = 0; cg < NCG; ++cg) acc[cg] = mfma_t<H16>(ah, bh[cg][u >> 1][u & 1], acc[cg]);
         if (u + PF < 2 * NT) lds_read_frag(ar[u % PF], la, (u + PF) * 1024);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -375,7 +407,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
             acc[0] = mfma_bf16(al[g & 1][X3 ? i : 0], bh[0][u >> 1][u & 1], acc[0]);
           } else {
 #pragma unroll
-            for (int cg = 0; cg < NCG; ++cg) acc[cg] = mfma_bf16(ab[g & 1][i], bh[cg][u >> 1][u & 1], acc[cg]);
+            for (int cg = 0; cg < NCG; ++cg) acc[cg] = mfma_t<H16>(ab[g & 1][i], bh[cg][u >> 1][u & 1], acc[cg]);
           }
         }
         if (g + 2 < NG) ldgrp(g + 2, g & 1);
@@ -540,15 +572,16 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
     // SG: selection operands of the transposing MFMAs: B_s[k][j] = [j == 16 s + k]; lane (j, hh) holds k = 8 hh .. 8 hh + 7
     u32x4 sel[2];
     auto transpose_tile = [&](const u32x4* frag) -> f32x16 {       // D[n][j] = position 16 s + k of sample n, j = 16 s + k
-      f32x16 d = mfma_bf16(frag[0], sel[0], (f32x16){0.f});
-      return mfma_bf16(frag[1], sel[1], d);
+      f32x16 d = mfma_t<H16>(frag[0], sel[0], (f32x16){0.f});
+      return mfma_t<H16>(frag[1], sel[1], d);
     };
     if constexpr (SG) {
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const int e = col - 16 * s2 - 8 * hh;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) sel[s2][q] = (e == 2 * q) ? 0x00003f80u : ((e == 2 * q + 1) ? 0x3f800000u : 0u);
+        for (int q = 0; q < 4; ++q)      // 1.0 in the operand type: bf16 0x3f80, f16 0x3c00
+          sel[s2][q] = (e == 2 * q) ? (H16 ? 0x00003c00u : 0x00003f80u) : ((e == 2 * q + 1) ? (H16 ? 0x3c000000u : 0x3f800000u) : 0u);
       }
 #pragma unroll
       for (int cg = 0; cg < NCG; ++cg) {
@@ -571,11 +604,19 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
       }
     }
     if (BWD) {
-      // ---------------- input-gradient chain, bf16 operands, fp32 accumulate
+      // ---------------- input-gradient chain, 16-bit operands, fp32 accumulate.  bf16: dZ_l.  H16: J_l = dZ_l / g.
       u32x4 dz[NCG][NT][2];
 #pragma unroll
       for (int cg = 0; cg < NCG; ++cg) {
-        if (!SG && hh == 0) a.graw[m[cg]] = g[cg];
+        if ((H16 || !SG) && hh == 0) a.graw[m[cg]] = g[cg];
+        if constexpr (H16) {
+          float gm = fabsf(g[cg]);
+#pragma unroll
+          for (int sh = 16; sh >= 1; sh >>= 1) gm = fmaxf(gm, __shfl_xor(gm, sh));
+          // integer max of non-negative float bit patterns: order-independent, so the result is deterministic
+          if (lane == 0 && gm > 0.f) atomicMax(a.gmax, __builtin_bit_cast(uint32_t, gm));
+        }
+        const float gs = H16 ? 1.f : g[cg];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const unsigned b32 = mask_expand(mk16[((N * NT + t) * NCG + cg) * NTH + tid]);
@@ -583,8 +624,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const f32x4 w4 = wp[q];
-            dz[cg][t][q >> 1][2 * (q & 1)] = pack2(w4[0] * g[cg], w4[1] * g[cg]) & halfmask(b32, 2 * q);
-            dz[cg][t][q >> 1][2 * (q & 1) + 1] = pack2(w4[2] * g[cg], w4[3] * g[cg]) & halfmask(b32, 2 * q + 1);
+            dz[cg][t][q >> 1][2 * (q & 1)] = pack2t<H16>(w4[0] * gs, w4[1] * gs) & halfmask(b32, 2 * q);
+            dz[cg][t][q >> 1][2 * (q & 1) + 1] = pack2t<H16>(w4[2] * gs, w4[3] * gs) & halfmask(b32, 2 * q + 1);
           }
         }
       }
@@ -618,7 +659,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
             const unsigned b32 = mask_expand(mw[cg]);
 #pragma unroll
             for (int q = 0; q < 8; ++q)
-              dn[cg][t][q >> 2][q & 3] = pack2(acc[cg][2 * q], acc[cg][2 * q + 1]) & halfmask(b32, q);
+              dn[cg][t][q >> 2][q & 3] = pack2t<H16>(acc[cg][2 * q], acc[cg][2 * q + 1]) & halfmask(b32, q);
           }
           STAMP(6);
         }
@@ -634,13 +675,17 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
           float tn, dx, dy, dzz;
           ray_param(a, sp[cg], tn, dx, dy, dzz);
           const float t0 = __shfl(tn, 0);          // the group's first sample: c = its point, t_0 = its ray parameter
-          const f32x16 dT = __builtin_amdgcn_mfma_f32_32x32x2f32(hh == 0 ? tn - t0 : 0.f, 1.f, (f32x16){0.f}, 0, 0, 0);
+          // per-sample weights of the two sums in the C layout: bf16: (1, t_n - t_0); H16 (d = J = dZ / g): (g_n, g_n (t_n - t_0))
+          const float w1 = H16 ? g[cg] * (tn - t0) : tn - t0;
+          const f32x16 dT = __builtin_amdgcn_mfma_f32_32x32x2f32(hh == 0 ? w1 : 0.f, 1.f, (f32x16){0.f}, 0, 0, 0);
+          f32x16 gT = {0.f};
+          if constexpr (H16) gT = __builtin_amdgcn_mfma_f32_32x32x2f32(hh == 0 ? g[cg] : 0.f, 1.f, (f32x16){0.f}, 0, 0, 0);
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
             const f32x16 d = transpose_tile(dz[cg][t]);
             float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s0 += d[r]; s1 = fmaf(dT[r], d[r], s1); }
+            for (int r = 0; r < 16; ++r) { s0 = H16 ? fmaf(gT[r], d[r], s0) : s0 + d[r]; s1 = fmaf(dT[r], d[r], s1); }
             s0 += __shfl_xor(s0, 32);
             s1 += __shfl_xor(s1, 32);
             rec[F + hh * F + 32 * t + col] = hh ? s1 : s0;
@@ -674,7 +719,11 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
 // stash position <-> feature index: swap bits 2 and 3 (self-inverse); see the stash stores of k_chain_bf16
 __device__ __forceinline__ int fperm(int p) { return (p & ~12) | ((p & 4) << 1) | ((p & 8) >> 1); }
 
-template <int F>
+// H16: the stashes hold f16 H_{l-1} and the NORMALISED chain J_l = dZ_l / g; the kernel contracts
+//   dW_l Ls = sum_n J_l[n][o] * (g_n Ls) H_{l-1}[n][i]   on v_mfma_f32_32x32x16_f16,
+// scaling the B fragments by packed (g Ls) pairs (one v_pk_mul_f16 per dword; the pairs are the same for all lanes of a
+// half-wave, a broadcast LDS read).  Ls = 2^-e from the chunk's max |g| (wgrad_scale_exp); the reduce kernels undo it.
+template <int F, bool H16 = false>
 __global__ void __launch_bounds__(512) k_wgrad_bf16(const WgradArgs a) {
   constexpr int NT = F / 32;
   constexpr int TR = NT >= 2 ? NT / 2 : 1, WR = NT / TR;   // row tiles per wave, waves along rows
@@ -685,9 +734,13 @@ __global__ void __launch_bounds__(512) k_wgrad_bf16(const WgradArgs a) {
                                              // four chunks a transpose-read touches fall on disjoint banks
   constexpr int IMG = NCH * CS;              // one operand image
   constexpr int RB = 2 * F;
+  constexpr int GOFF = 4 * IMG;              // H16: behind the two stages, per stage [64 x f16 (g Ls) | 64 x f32 (g Ls)]
+  constexpr int GST = KB * 2 + KB * 4;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, hh = lane >> 5;
   const int layer = blockIdx.y + 1, split = blockIdx.x;
+  float ls = 1.f;
+  if constexpr (H16) ls = ldexpf(1.f, -wgrad_scale_exp(a.gmax));
   const char* A = (const char*)a.stash_dz + (size_t)layer * a.stride_rows * RB;
   const char* B = (const char*)a.stash_h + (size_t)(layer - 1) * a.stride_rows * RB;
   int64_t r0 = (int64_t)split * a.rows_per_split;
@@ -731,13 +784,23 @@ __global__ void __launch_bounds__(512) k_wgrad_bf16(const WgradArgs a) {
     return __builtin_bit_cast(u32x4, f);
   };
 
-  if (nst > 0) stage_load(0, 0);
+  // H16: g of the stage's 64 samples: loaded by the first wave with the stage's DMA, written to LDS once it has landed
+  float greg = 0.f;
+  auto g_load = [&](int st) { if (H16 && tid < KB) greg = a.graw[r0 + (int64_t)st * KB + tid]; };
+  if (nst > 0) { stage_load(0, 0); g_load(0); }
   for (int st = 0; st < nst; ++st) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (H16 && tid < KB) {
+      const float gs = greg * ls;
+      char* gb = lds + GOFF + (st & 1) * GST;
+      *(_Float16*)(gb + tid * 2) = (_Float16)gs;
+      *(float*)(gb + KB * 2 + tid * 4) = gs;
+    }
     __syncthreads();
-    if (st + 1 < nst) stage_load(st + 1, (st + 1) & 1);
+    if (st + 1 < nst) { stage_load(st + 1, (st + 1) & 1); g_load(st + 1); }
     const char* sA = lds + (st & 1) * 2 * IMG;
     const char* sB = sA + IMG;
+    const char* sG = lds + GOFF + (st & 1) * GST;
     if (active) {
 #pragma unroll
       for (int ks = 0; ks < KB / 16; ++ks) {
@@ -746,20 +809,28 @@ __global__ void __launch_bounds__(512) k_wgrad_bf16(const WgradArgs a) {
         for (int i = 0; i < TR; ++i) af[i] = tr_frag(sA, ks, 32 * (wr * TR + i));
 #pragma unroll
         for (int j = 0; j < TC; ++j) bf[j] = tr_frag(sB, ks, 32 * (wc * TC + j));
+        if constexpr (H16) {
+          // element j of a fragment is stage row 16 ks + 8 hh + j: four packed (g Ls) pairs, the same for the whole half-wave
+          // (whole-vector multiply: element-wise writes through bf[j][q] were miscompiled by hipcc 7.2 into a chain on element 0)
+          const f16x8_t gp = *(const f16x8_t*)(sG + (ks * 16 + 8 * hh) * 2);
+#pragma unroll
+          for (int j = 0; j < TC; ++j) bf[j] = __builtin_bit_cast(u32x4, __builtin_bit_cast(f16x8_t, bf[j]) * gp);
+        }
 #pragma unroll
         for (int i = 0; i < TR; ++i)
 #pragma unroll
-          for (int j = 0; j < TC; ++j) acc[i][j] = mfma_bf16(af[i], bf[j], acc[i][j]);
+          for (int j = 0; j < TC; ++j) acc[i][j] = mfma_t<H16>(af[i], bf[j], acc[i][j]);
       }
     }
-    // bias gradient: column sums of the dZ image on the VALU (512 threads: F positions x 512/F row groups)
+    // bias gradient: column sums of the dZ image on the VALU (512 threads: F positions x 512/F row groups); H16: sum_n (g_n Ls) J
     {
       const int f = tid % F, part = tid / F;
       constexpr int PARTS = 512 / F;
 #pragma unroll 8
       for (int r = part; r < KB; r += PARTS) {
         const unsigned short v = *(const unsigned short*)(sA + (f >> 3) * CS + r * 16 + (f & 7) * 2);
-        bsum += __builtin_bit_cast(float, (unsigned)v << 16);
+        if constexpr (H16) bsum = fmaf(*(const float*)(sG + KB * 2 + r * 4), (float)__builtin_bit_cast(_Float16, v), bsum);
+        else bsum += __builtin_bit_cast(float, (unsigned)v << 16);
       }
     }
   }
@@ -792,7 +863,7 @@ __global__ void __launch_bounds__(512) k_wgrad_bf16(const WgradArgs a) {
 // grid = (n_records, F/64 * (ENC ? 4 : 1)), block = 256 = 8 chunk columns x 32 rows: a wave reads two contiguous
 // 512-byte runs of the chunk-major stash.  blockIdx.y selects 64 stash positions (and, with an encoding, which
 // 2 of each chunk's 8 positions this block accumulates, to bound the accumulator count).
-template <int F, bool ENC>
+template <int F, bool ENC, bool H16 = false>
 __global__ void __launch_bounds__(256) k_small_grads_bf16(const WgradArgs a) {
   constexpr int KMAX = ENC ? 64 : 4;
   constexpr int PPT = ENC ? 2 : 8;
@@ -830,8 +901,9 @@ __global__ void __launch_bounds__(256) k_small_grads_bf16(const WgradArgs a) {
       const int e8 = ENC ? 2 * sub + i : i;                   // element of the 16-byte chunk
       const unsigned dw = e8 < 2 ? x[0] : (e8 < 4 ? x[1] : (e8 < 6 ? x[2] : x[3]));
       const unsigned hw = e8 < 2 ? y[0] : (e8 < 4 ? y[1] : (e8 < 6 ? y[2] : y[3]));
-      const float d = (e8 & 1) ? bf_hi(dw) : bf_lo(dw);
-      const float h = (e8 & 1) ? bf_hi(hw) : bf_lo(hw);
+      // H16: the stash holds J_0 = dZ_0 / g
+      const float d = ((e8 & 1) ? hi_t<H16>(dw) : lo_t<H16>(dw)) * (H16 ? gr : 1.f);
+      const float h = (e8 & 1) ? hi_t<H16>(hw) : lo_t<H16>(hw);
       bs[i] += d;
       so[i] = fmaf(gr, h, so[i]);
 #pragma unroll
@@ -928,6 +1000,7 @@ __global__ void __launch_bounds__(256) k_reduce_small(const ReduceArgs a) {
   a.grad[dst] += s;
 }
 
+#ifndef AFX_TEMPLATES_ONLY
 // ---------------------------------------------------------------------------------------
 // Weight re-tiling for the bf16 kernels.  parts = 2 also stores the lo parts (X3 forward) as a second stream.
 // ---------------------------------------------------------------------------------------
@@ -936,6 +1009,7 @@ struct PrepArgs16 {
   char* prepared;
   int32_t F, n_hidden, k0, nk0, parts;
   uint32_t slab0_off, slab0_bytes, fwd_off, slabh_stride, bwd_off, slabt_bytes, lo_off;
+  int32_t h16;          // hidden slabs (forward and transposed) in f16; the first layer stays split bf16
 };
 
 __device__ __forceinline__ unsigned short bf16_rne(float x) { return (unsigned short)(pack2(x, 0.f) & 0xffffu); }
@@ -985,9 +1059,11 @@ __global__ void k_prepare_bf16(const PrepArgs16 p) {
     const int k = 32 * tp + 16 * s + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
     const float w = isb ? W[(size_t)k * F + r] : W[(size_t)r * F + k];
     const unsigned short hi = bf16_rne(w);
-    const unsigned short val = part == 0 ? hi : bf16_rne(w - __builtin_bit_cast(float, (unsigned)hi << 16));
+    unsigned short val = part == 0 ? hi : bf16_rne(w - __builtin_bit_cast(float, (unsigned)hi << 16));
+    if (p.h16) val = __builtin_bit_cast(unsigned short, (_Float16)w);
     unsigned short* dst = isb ? (unsigned short*)(p.prepared + p.bwd_off + slab * p.slabt_bytes)
                               : (unsigned short*)(p.prepared + (part == 0 ? p.fwd_off : p.lo_off) + slab * p.slabt_bytes);
     dst[e] = val;
   }
 }
+#endif  // AFX_TEMPLATES_ONLY

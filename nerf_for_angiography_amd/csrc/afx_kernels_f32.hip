@@ -32,6 +32,16 @@ __device__ __forceinline__ void glds_copy(const char* g, char* l, uint32_t bytes
 
 __device__ __forceinline__ int rowperm(int j) { return (j & 3) + 8 * (j >> 2); }
 
+// Power-of-two scale of the weight-gradient contraction (f16 mode, afx_kernels_bf16.hip): the B operand is (g_n Ls) H[n] in f16, Ls = 2^-e with
+// gmax = m 2^e, m in [0.5, 1), so that g_n Ls <= 1; terms more than 2^24 below the largest one flush, which no sum notices.
+__device__ __forceinline__ int wgrad_scale_exp(const uint32_t* gmax_bits) {
+  const float gm = __builtin_bit_cast(float, *gmax_bits);
+  if (!(gm > 0.f) || !(gm < 3.0e38f)) return 0;
+  int e;
+  (void)frexpf(gm, &e);
+  return e;
+}
+
 // One element of CPPN.pos_enc's output (model/CPPN.py:207-234) for input point (px,py,pz).
 // aux (LDS): BARF [freq(3L) | weight(3L)], FOURIER [coef(3L)].
 __device__ __forceinline__ float enc_value(int k, float px, float py, float pz, const float* aux,
@@ -520,6 +530,7 @@ __global__ void k_reduce_w(const ReduceArgs a) {
   for (int sp = 0; sp < a.n_splits; ++sp) s += a.partial[((size_t)layer * a.n_splits + sp) * F * F + e];
   // flat layout: W0[F,k0] b0[F] then (W_l[F,F] b_l[F])*, Wout[F] bout
   size_t off = layer == 0 ? 0 : (size_t)F * a.k0 + F + (size_t)(layer - 1) * (F * F + F);
+  if (a.gmax) s *= ldexpf(1.f, wgrad_scale_exp(a.gmax));       // f16 mode (hidden layers only reach here): undo Ls, exact
   a.grad[off + (size_t)row * ncr + c] += s;
 }
 
@@ -535,6 +546,7 @@ __global__ void k_reduce_b(const ReduceArgs a) {
     if (y == a.n_hidden + 1 && f == 0) sg += P[F];
   }
   const size_t hidden0 = (size_t)F * a.k0 + F;
+  if (a.gmax) s *= ldexpf(1.f, wgrad_scale_exp(a.gmax));
   if (y == 0) a.grad[(size_t)F * a.k0 + f] += s;
   else if (y <= a.n_hidden) a.grad[hidden0 + (size_t)(y - 1) * (F * F + F) + (size_t)F * F + f] += s;
   else {
@@ -544,6 +556,7 @@ __global__ void k_reduce_b(const ReduceArgs a) {
   }
 }
 
+#ifndef AFX_TEMPLATES_ONLY      // plain kernels below: defined once, in the host translation unit
 // ---------------------------------------------------------------------------------------
 // Weight re-tiling (afx_prepare_weights), fp32.
 // ---------------------------------------------------------------------------------------
@@ -828,3 +841,4 @@ __global__ void k_fine_depths(const float* zc, int z_per_ray, const float* wc, c
     else o[p] = smp[k++];
   }
 }
+#endif  // AFX_TEMPLATES_ONLY

@@ -1,7 +1,7 @@
 """Ray-batch data parallelism: one process per GPU, torch.distributed ("nccl" == RCCL on ROCm, over xGMI).
 
 The reference is single-device (nerf/run_nerf_acc.py:23).  Rays are independent, the only coupling is the
-shared MLP, so the path shards by rays with ONE collective per step: a sum all-reduce of the flat fp32
+shared MLP, so the path shards by rays with ONE collective per step: a SUM all-reduce of the flat fp32
 gradient buffer (527 621 floats = 2.1 MB at 8x256), issued on the flat buffer before it is split into
 per-parameter views.  At that size the collective is latency-bound; one call is the whole cost."""
 from __future__ import annotations
@@ -48,19 +48,26 @@ def broadcast_parameters(model, src: int = 0):
 
 
 class GradSync:
-    """Average parameter gradients over ranks with one all-reduce of the flat gradient buffer.
+    """SUM the flat parameter gradient over ranks with one all-reduce (no division).
 
-    Each rank computes the mean loss over ITS rays; with equal shard sizes the mean of the per-rank
-    gradients equals the gradient of the mean loss over the global batch."""
+    Contract (one, everywhere): the loss of a step is the mean over the GLOBAL ray batch, so every rank seeds its
+    backward with dL/dpixel = 2 (pixel - target) / n_global - `render.train_step_mse(..., n_global=...)` bakes
+    1/n_global into the kernel, the autograd path divides the summed squared error by n_global - and the per-rank
+    gradients ADD UP to the single-GPU gradient of the union batch.  That is exact for unequal shards too (a mean of
+    per-rank means is not).  `seconds` accumulates nothing on the host: time the collective with events around it."""
 
     def __init__(self, group=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.on_call = None            # optional (before, after) hooks, e.g. event records for bench.py
 
     def __call__(self, flat_grad: torch.Tensor):
         if self.world > 1:
+            if self.on_call is not None:
+                self.on_call[0]()
             dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
-            flat_grad.div_(self.world)
+            if self.on_call is not None:
+                self.on_call[1]()
 
     def install(self):
         _render._grad_hook = self

@@ -55,11 +55,11 @@ class Engine:
     """One CPPN geometry on one GPU."""
 
     def __init__(self, width: int, n_hidden: int, enc: str = "none", n_freq: int = 0,
-                 max_workspace_bytes: int = 24 << 30):
-        self.lib = _lib.load()
+                 max_workspace_bytes: int = 24 << 30, variant: str = ""):
+        self.lib = _lib.load(variant)
         self.desc = ModelDesc(3, _lib.ENC[enc], int(n_freq), int(width), int(n_hidden))
         h = C.c_void_p()
-        _lib.check(self.lib.afx_create(C.byref(self.desc), C.byref(h)), "afx_create")
+        self._check(self.lib.afx_create(C.byref(self.desc), C.byref(h)), "afx_create")
         self.h = h
         self.width, self.n_hidden, self.enc = width, n_hidden, enc
         self.param_count = int(self.lib.afx_query(h, _lib.Q_PARAM_COUNT, 0, 0, 0))
@@ -67,6 +67,11 @@ class Engine:
         self.max_workspace_bytes = int(max_workspace_bytes)
         self._prepared = {}      # prec -> (buffer, version key)
         self._ws = None
+        self._ws_captured = False
+        self._retired = []       # workspaces a captured graph still points at
+
+    def _check(self, rc, what):
+        _lib.check(rc, what, self.lib)
 
     def __del__(self):
         try:
@@ -80,18 +85,18 @@ class Engine:
     KERNELS = {"chain_fwd": 0, "chain_bwd": 1, "wgrad": 2}
 
     def profile(self, on: bool):
-        _lib.check(self.lib.afx_profile_enable(self.h, int(on)), "afx_profile_enable")
+        self._check(self.lib.afx_profile_enable(self.h, int(on)), "afx_profile_enable")
 
     def profile_read(self, kernel: str):
         """(total device ms, launches) of one kernel kind since the last read (HIP events on the launch stream)."""
         ms, n = C.c_double(), C.c_int64()
-        _lib.check(self.lib.afx_profile_read(self.h, self.KERNELS[kernel], C.byref(ms), C.byref(n)), "afx_profile_read")
+        self._check(self.lib.afx_profile_read(self.h, self.KERNELS[kernel], C.byref(ms), C.byref(n)), "afx_profile_read")
         return ms.value, n.value
 
     # ---- parameter layout ------------------------------------------------------------------
     def layout(self, layer: int):
         wo, bo, r, c = C.c_int64(), C.c_int64(), C.c_int32(), C.c_int32()
-        _lib.check(self.lib.afx_param_layout(self.h, layer, C.byref(wo), C.byref(bo), C.byref(r), C.byref(c)),
+        self._check(self.lib.afx_param_layout(self.h, layer, C.byref(wo), C.byref(bo), C.byref(r), C.byref(c)),
                    "afx_param_layout")
         return wo.value, bo.value, r.value, c.value
 
@@ -100,9 +105,20 @@ class Engine:
         return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
     def _workspace(self, nbytes: int, device) -> torch.Tensor:
+        """The (one) workspace buffer, grown on demand.  A HIP graph captured over a call keeps the buffer's address:
+        a buffer that a capture has seen is never freed when a later, larger request replaces it, and growing it
+        DURING a capture is refused (run the step once eagerly first - that sizes it)."""
+        capturing = device.type == "cuda" and torch.cuda.is_current_stream_capturing()
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
+            if capturing:
+                raise AfxError("the workspace must be sized before graph capture: run the same call once eagerly first")
+            if self._ws is not None and self._ws_captured:
+                self._retired.append(self._ws)
             self._ws = None
             self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            self._ws_captured = False
+        if capturing:
+            self._ws_captured = True
         return self._ws
 
     # ---- weights -----------------------------------------------------------------------------
@@ -122,7 +138,7 @@ class Engine:
             nbytes, dtype=torch.uint8, device=flat.device)
         if enc_aux is not None:
             enc_aux = _f32(enc_aux, "enc_aux", flat.device)
-        _lib.check(self.lib.afx_prepare_weights(self.h, p, _ptr(flat), _ptr(enc_aux), _ptr(buf), nbytes,
+        self._check(self.lib.afx_prepare_weights(self.h, p, _ptr(flat), _ptr(enc_aux), _ptr(buf), nbytes,
                                                 self._stream(flat.device)), "afx_prepare_weights")
         self._prepared[prec] = (buf, key)
         return buf
@@ -134,7 +150,7 @@ class Engine:
         if pts.dim() != 2 or pts.shape[1] != 3:
             raise ValueError(f"points: shape {tuple(pts.shape)}, expected [P,3]")
         out = torch.empty(pts.shape[0], dtype=torch.float32, device=dev)
-        _lib.check(self.lib.afx_mlp_infer(self.h, _lib.PREC[prec], _ptr(prepared), _ptr(pts), pts.shape[0], _ptr(out),
+        self._check(self.lib.afx_mlp_infer(self.h, _lib.PREC[prec], _ptr(prepared), _ptr(pts), pts.shape[0], _ptr(out),
                                           int(apply_sigmoid), self._stream(dev)), "afx_mlp_infer")
         return out
 
@@ -147,7 +163,7 @@ class Engine:
             raise ValueError("d_out: one value per point expected")
         full = int(self.lib.afx_query(self.h, _lib.Q_BWD_WORKSPACE_FULL, 0, n, _lib.PREC[prec]))
         ws = self._workspace(min(full, self.max_workspace_bytes), dev)
-        _lib.check(self.lib.afx_mlp_backward(self.h, _lib.PREC[prec], _ptr(prepared), _ptr(pts), n, _ptr(d_out),
+        self._check(self.lib.afx_mlp_backward(self.h, _lib.PREC[prec], _ptr(prepared), _ptr(pts), n, _ptr(d_out),
                                              _ptr(grad_flat), _ptr(ws), ws.numel(), self._stream(dev)),
                    "afx_mlp_backward")
 
@@ -206,7 +222,7 @@ class Engine:
         a, keep = self._render_args(spec, dev, pixel, sigma, tau)
         ws = self._workspace(int(self.lib.afx_query(self.h, _lib.Q_FWD_WORKSPACE, spec.n_rays, spec.n_samples, 0)), dev)
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
-        _lib.check(self.lib.afx_render_forward(self.h, _lib.PREC[prec], _ptr(prepared), C.byref(a), self._stream(dev)),
+        self._check(self.lib.afx_render_forward(self.h, _lib.PREC[prec], _ptr(prepared), C.byref(a), self._stream(dev)),
                    "afx_render_forward")
         del keep
         return pixel, sigma, tau
@@ -219,7 +235,7 @@ class Engine:
         full = int(self.lib.afx_query(self.h, _lib.Q_BWD_WORKSPACE_FULL, spec.n_rays, spec.n_samples, _lib.PREC[prec]))
         ws = self._workspace(min(full, self.max_workspace_bytes), dev)
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
-        _lib.check(self.lib.afx_render_backward(self.h, _lib.PREC[prec], _ptr(prepared), C.byref(a), _ptr(d_pixel),
+        self._check(self.lib.afx_render_backward(self.h, _lib.PREC[prec], _ptr(prepared), C.byref(a), _ptr(d_pixel),
                                                 _ptr(grad_flat), self._stream(dev)), "afx_render_backward")
         del keep
 
@@ -236,7 +252,7 @@ class Engine:
                                       _lib.PREC[prec]))
         ws = self._workspace(min(full, self.max_workspace_bytes), dev)
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
-        _lib.check(self.lib.afx_train_step_mse(self.h, _lib.PREC[prec], _ptr(prepared), C.byref(a), _ptr(target),
+        self._check(self.lib.afx_train_step_mse(self.h, _lib.PREC[prec], _ptr(prepared), C.byref(a), _ptr(target),
                                                float(inv_n), _ptr(grad_flat), self._stream(dev)), "afx_train_step_mse")
         del keep
         return pixel

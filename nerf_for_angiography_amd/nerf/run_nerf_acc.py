@@ -47,8 +47,8 @@ def build_parser():
     p.add_argument('--sample_size', type=int, default=75, help='rays per dimension per iteration (75^2 = 5625)')
     p.add_argument('--depth_samples', type=int, default=300)
     p.add_argument('--pos_enc', default='none', choices=['none', 'barf', 'fourier'])
-    p.add_argument('--precision', default='bf16', choices=['f32', 'bf16x3', 'bf16'])
-    p.add_argument('--eval_precision', default='bf16x3', choices=['f32', 'bf16x3', 'bf16'])
+    p.add_argument('--precision', default='f16', choices=['f32', 'bf16x3', 'bf16', 'f16'])
+    p.add_argument('--eval_precision', default='f16', choices=['f32', 'bf16x3', 'bf16', 'f16'])
     p.add_argument('--log_dir', default='runs/afx')
     p.add_argument('--seed', type=int, default=0)
     p.add_argument('--out_bias_init', type=float, default=-5.0,

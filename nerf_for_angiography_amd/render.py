@@ -123,11 +123,11 @@ def train_step_mse(model, spec: RenderSpec, target: torch.Tensor, n_global: Opti
     Replaces `pred = render(...); loss = mse_loss(pred, target); loss.backward()` (nerf/run_nerf_acc.py:287-306):
     the gradients are ACCUMULATED into `.grad` of the model's Linear parameters exactly as loss.backward() would,
     so `optimizer.zero_grad(); train_step_mse(...); optimizer.step()` is the training iteration.  The forward pass
-    is the backward kernel's own recompute (bf16), nothing is rendered twice.  Returns (loss, pixels), detached.
+    is the backward kernel's own forward (f16 / bf16 operands), nothing is rendered twice.  Returns (loss, pixels), detached.
     n_global: total rays of the step across all ranks (default: this batch) - the mean is over that count."""
     _check_model(model)
     if model.precision == "f32":
-        raise NotImplementedError("train_step_mse needs a bf16 precision; with 'f32' use render + autograd")
+        raise NotImplementedError("train_step_mse needs a 16-bit precision (f16, bf16, bf16x3); with 'f32' use render + autograd")
     n = int(n_global) if n_global else int(spec.n_rays)
     flat_grad = torch.zeros(model.engine.param_count, dtype=torch.float32, device=model.flat_params.device)
     s_pad = (spec.n_samples + 31) // 32 * 32

@@ -49,7 +49,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):
     from nerf_for_angiography_amd import _lib
-    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "_libs", {})
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.AfxError, match="not built"):
         _lib.load()
@@ -290,6 +290,33 @@ def test_bench_flop_model():
 
 
 # ---------------------------------------------------------------- data-parallel path on 2 gloo ranks
+def _dp_problem():
+    """A seeded global ray batch (37 rays: the two shards are unequal) for the data-parallel contract test."""
+    g = torch.Generator().manual_seed(99)
+    n = 37
+    o = torch.tensor([[0.0, 0.0, 1500.0]]).repeat(n, 1)
+    d = torch.nn.functional.normalize(torch.randn(n, 3, generator=g) * 0.03 + torch.tensor([0, 0, -1.0]), dim=-1)
+    tgt = torch.rand(n, generator=g)
+    return o, d, tgt
+
+
+def _dp_flat_grad(m, o, d, tgt, n_global):
+    """Flat gradient of sum_r (pixel_r - target_r)^2 / n_global over the given rays, through the module's
+    torch-operator path (CPU) and the reference's acc compositing - what a rank's fused kernels produce on a GPU."""
+    from nerf_for_angiography_amd.nerf.nerf_helpers_acc import acc_ray_marching, acc_render_volume_density
+    s = 16
+    ri, ts, te = acc_ray_marching(m, None, None, o, d, s, 1400.0, 1600.0)
+    pos = o[ri.long()] + d[ri.long()] * (ts + te) / 2.0
+    pix, _ = acc_render_volume_density(m(pos), ri, ts, te, o.shape[0], s)
+    loss = ((pix - tgt) ** 2).sum() / n_global
+    m.zero_grad()
+    loss.backward()
+    flat = torch.zeros(m.flat_params.numel())
+    for p, gv in zip(m._hip_params(), m._split_grad(flat)):
+        gv.copy_(p.grad)
+    return flat
+
+
 def _dp_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
@@ -300,19 +327,26 @@ def _dp_worker(rank, world, port, q):
     r, w, dev = afx_dist.init_from_env("gloo")
     torch.manual_seed(rank)                       # different weights per rank until the broadcast
     m = CPPN(model_def(4, 64))
+    with torch.no_grad():
+        m.output_linear[0].bias.fill_(-4.0)
     afx_dist.broadcast_parameters(m)
     flat0 = m.flat_params.clone()
     sync = afx_dist.GradSync().install()
     assert render._grad_hook is sync
-    g = torch.full((m.flat_params.numel(),), float(rank + 1))
-    render._grad_hook(g)                          # what _RenderFn.backward / train_step_mse call
-    start, count = afx_dist.shard(10, r, w)
-    q.put((rank, flat0[:8].tolist(), float(g[0]), start, count))
+    o, d, tgt = _dp_problem()
+    n = o.shape[0]
+    start, count = afx_dist.shard(n, r, w)
+    g = _dp_flat_grad(m, o[start:start + count], d[start:start + count], tgt[start:start + count], n)
+    render._grad_hook(g)                          # what _RenderFn.backward / train_step_mse call: SUM over ranks
+    g_union = _dp_flat_grad(m, o, d, tgt, n) if rank == 0 else None      # the 1-rank gradient of the union batch
+    q.put((rank, flat0[:8].tolist(), g.tolist(), None if g_union is None else g_union.tolist(), start, count))
     afx_dist.GradSync.uninstall()
     dist.destroy_process_group()
 
 
 def test_two_rank_gloo_grad_sync_and_sharding():
+    """2 ranks, UNEQUAL ray shards (19 + 18 rays), real gradients: the all-reduced gradient equals the 1-rank
+    gradient of the union batch (loss = mean over the global batch, SUM all-reduce, no division)."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -320,14 +354,17 @@ def test_two_rank_gloo_grad_sync_and_sharding():
     procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=120) for _ in procs)
+    res = sorted(q.get(timeout=180) for _ in procs)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (r0, w0, g0, s0, c0), (r1, w1, g1, s1, c1) = res
+    (r0, w0, g0, u0, s0, c0), (r1, w1, g1, u1, s1, c1) = res
     assert w0 == w1                                # rank 0's weights everywhere
-    assert g0 == g1 == 1.5                         # mean of the per-rank gradients (1 and 2)
-    assert (s0, c0, s1, c1) == (0, 5, 5, 5)
+    assert g0 == g1                                # identical synced gradients on both ranks
+    assert (s0, c0, s1, c1) == (0, 19, 19, 18)
+    g0, u0 = np.asarray(g0), np.asarray(u0)
+    assert np.linalg.norm(u0) > 0
+    assert rel_l2(g0, u0) < 1e-5                   # N-rank == 1-rank up to fp32 summation order
     from nerf_for_angiography_amd.dist import shard
     assert [shard(10, r, 4) for r in range(4)] == [(0, 3), (3, 3), (6, 2), (8, 2)]
 
