@@ -364,8 +364,7 @@ def cpu_leg(model, args, pose, target, W, H, focal, near, far, S, device, render
     return {"cpu_baseline": {"value": round(args.cpu_rays * S / best, 1), "unit": "ray-samples/s",
                              "cores": torch.get_num_threads(), "kind": "port",
                              "sample": f"{args.cpu_rays} rays x {S} samples of the same projection, {args.layers}x{args.width} MLP, "
-                                       "fp32 PyTorch-CPU oracle, fwd+bwd+Adam, best of 3 timed steps after 1 warm-up; "
-                                       cpu_note},
+                                       "fp32 PyTorch-CPU oracle, fwd+bwd+Adam, best of 3 timed steps after 1 warm-up; " + cpu_note},
             "parity_vs_cpu_oracle": {"rays": args.cpu_rays, "precision": keep, "bar": PARITY_BAR,
                                      "rel_l2": rel(pix_init_gpu[keep], pix_init_cpu),
                                      "psnr_db": round(-10 * np.log10(max(mse, 1e-30)), 2),
