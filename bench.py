@@ -30,9 +30,10 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0, "f16": 2500.0}     # MI355X_MICROARCH.md: dense MFMA peaks (f16 = bf16 rate)
+PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0, "f16": 2500.0, "f16s8": 2500.0}     # MI355X_MICROARCH.md: dense MFMA peaks (f16 = bf16 rate)
 DTYPE_NAME = {"f32": "f32", "bf16x3": "bf16x3 (split bf16, f32 accumulate)", "bf16": "bf16 (f32 accumulate)",
-              "f16": "f16 (f32 accumulate; first layer split bf16)"}
+              "f16": "f16 (f32 accumulate; first layer split bf16)",
+              "f16s8": "f16 (f32 accumulate; first layer split bf16; backward stash kept as bf8)"}
 PARITY_BAR = 1e-4
 
 
@@ -52,7 +53,9 @@ def stash_bytes_per_sample(width, layers, precision, in_kernel_small=True):
         return 2 * (layers + 1) * width * esz, wgrad
     # 16-bit rays mode: H_N / dZ_0 are not stashed; per 32-sample group 3 x width + 8 floats of partial sums instead
     chain = wgrad + (3 * width + 8) * 4 / 32
-    if precision == "f16":
+    if precision == "f16s8":                              # one byte per stash element
+        chain, wgrad = chain - wgrad + wgrad // 2, wgrad // 2
+    if precision in ("f16", "f16s8"):
         chain += 4                                        # dL/draw per sample (the chain is normalised by it)
         wgrad += 4
     return chain, wgrad
@@ -83,7 +86,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--precision", default=os.environ.get("AFX_BENCH_PRECISION", "f16"), choices=["f32", "bf16x3", "bf16", "f16"])
+    ap.add_argument("--precision", default=os.environ.get("AFX_BENCH_PRECISION", "f16"), choices=["f32", "bf16x3", "bf16", "f16", "f16s8"])
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--samples", type=int, default=128)
     ap.add_argument("--layers", type=int, default=8)
@@ -331,7 +334,7 @@ def cpu_leg(model, args, pose, target, W, H, focal, near, far, S, device, render
         model.load_state_dict(state)
         out = {}
         with torch.no_grad():
-            for prec in dict.fromkeys([keep, "f16", "bf16x3", "bf16"]):
+            for prec in dict.fromkeys([keep, "f16", "bf16x3", "bf16"]):      # (f16s8 renders exactly as f16)
                 model.precision = prec
                 out[prec] = render_rays(model, o.to(device), d.to(device), S, near, far, mode="acc").rgb_map.cpu()
         model.precision = keep

@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libafx.so")
 
 ENC = {"none": 0, "barf": 1, "fourier": 2}
-PREC = {"f32": 0, "bf16x3": 1, "bf16": 2, "f16": 3}
+PREC = {"f32": 0, "bf16x3": 1, "bf16": 2, "f16": 3, "f16s8": 4}
 RAYS_ARRAYS, RAYS_POSE = 0, 1
 DEPTH_UNIFORM_MID, DEPTH_SHARED_Z, DEPTH_PER_RAY_Z = 0, 1, 2
 Q_PARAM_COUNT, Q_K0, Q_PREPARED_BYTES, Q_FWD_WORKSPACE, Q_BWD_WORKSPACE_MIN, Q_BWD_WORKSPACE_FULL = range(6)

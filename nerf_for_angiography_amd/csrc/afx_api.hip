@@ -84,10 +84,11 @@ struct PrepLayout {
   size_t total;
 };
 
-static inline bool is_bf16(int prec) { return prec == AFX_PREC_BF16 || prec == AFX_PREC_BF16X3 || prec == AFX_PREC_F16; }   // the 16-bit kernel family
+static inline bool is_f16(int prec) { return prec == AFX_PREC_F16 || prec == AFX_PREC_F16S8; }
+static inline bool is_bf16(int prec) { return prec == AFX_PREC_BF16 || prec == AFX_PREC_BF16X3 || is_f16(prec); }   // the 16-bit kernel family
 static inline int nk0_of(const afx_ctx* c) { return c->d.enc == AFX_ENC_NONE ? 1 : 4; }
 // samples per workgroup tile of the forward / backward chain kernel
-static inline int fwd_tile(int prec) { return (prec == AFX_PREC_BF16 || prec == AFX_PREC_F16) ? 256 : 128; }
+static inline int fwd_tile(int prec) { return (prec == AFX_PREC_BF16 || is_f16(prec)) ? 256 : 128; }
 static inline int bwd_tile(int prec) { return prec == AFX_PREC_F32 ? 128 : 256; }
 
 static PrepLayout prep_layout(const afx_ctx* c, int prec) {
@@ -278,7 +279,7 @@ static int check_dev(const afx_ctx* c, const char* who) {
 }
 
 static int check_prec(int prec, const char* who) {
-  if (prec != AFX_PREC_F32 && prec != AFX_PREC_BF16X3 && prec != AFX_PREC_BF16 && prec != AFX_PREC_F16) return fail(AFX_E_INVALID, "%s: unknown precision %d", who, prec);
+  if (prec != AFX_PREC_F32 && prec != AFX_PREC_BF16X3 && prec != AFX_PREC_BF16 && !is_f16(prec)) return fail(AFX_E_INVALID, "%s: unknown precision %d", who, prec);
   return AFX_OK;
 }
 
@@ -302,7 +303,7 @@ extern "C" int afx_prepare_weights(afx_ctx* c, int prec, const float* params, co
     q.params = params; q.prepared = (char*)prepared;
     q.F = c->d.width; q.n_hidden = c->d.n_hidden; q.k0 = c->k0; q.nk0 = nk0_of(c); q.parts = prec == AFX_PREC_BF16X3 ? 2 : 1;
     q.slab0_off = L.slab0_off; q.slab0_bytes = L.slab0_bytes; q.fwd_off = L.fwd_off; q.slabh_stride = L.slabh_stride;
-    q.bwd_off = L.bwd_off; q.slabt_bytes = L.slabt_bytes; q.lo_off = L.lo_off; q.h16 = prec == AFX_PREC_F16 ? 1 : 0;
+    q.bwd_off = L.bwd_off; q.slabt_bytes = L.slabt_bytes; q.lo_off = L.lo_off; q.h16 = is_f16(prec) ? 1 : 0;
     hipLaunchKernelGGL(k_prepare_bf16, dim3(512), dim3(256), 0, (hipStream_t)stream, q);
   }
   HIPCHK(hipGetLastError());
@@ -332,7 +333,8 @@ static int launch_chain_f(afx_ctx* c, int prec, bool bwd, const ChainArgs& a, si
   if (prec == AFX_PREC_BF16X3 && !bwd)
     return enc ? launch_chain_k(c, k_chain_bf16<F, true, true, false, 4>, which, a, lds, grid, st)
                : launch_chain_k(c, k_chain_bf16<F, true, false, false, 4>, which, a, lds, grid, st);
-  if (prec == AFX_PREC_F16) {
+  if (is_f16(prec)) {
+    if (bwd && a.small_part && a.stash8) return launch_chain_k(c, k_chain_bf16<F, false, false, true, 8, true, true, true>, which, a, lds, grid, st, 512);
     if (bwd && a.small_part) return launch_chain_k(c, k_chain_bf16<F, false, false, true, 8, true, true>, which, a, lds, grid, st, 512);
     if (bwd)
       return enc ? launch_chain_k(c, k_chain_bf16<F, false, true, true, 8, false, true>, which, a, lds, grid, st, 512)
@@ -351,7 +353,7 @@ static int launch_chain_f(afx_ctx* c, int prec, bool bwd, const ChainArgs& a, si
 static int launch_chain(afx_ctx* c, int prec, bool bwd, const ChainArgs& a, hipStream_t st) {
   const int F = c->d.width, N = c->d.n_hidden;
   size_t lds = (size_t)a.small_bytes_pad + (size_t)(is_bf16(prec) ? chain_ring(bwd) : 2) * a.slot_bytes;
-  const int ncg = (is_bf16(prec) && (bwd || prec == AFX_PREC_BF16 || prec == AFX_PREC_F16)) ? 2 : 1;
+  const int ncg = (is_bf16(prec) && (bwd || prec == AFX_PREC_BF16 || is_f16(prec))) ? 2 : 1;
   if (bwd) lds += (size_t)(N + 1) * ((c->nt + 1) / 2) * ncg * 256 * 4 + 256;   // ReLU masks + per-group optical depths
   if (lds > 160 * 1024) return fail(AFX_E_INVALID, "model needs %zu B of LDS (> 160 KiB)", lds);
   const int tiles = a.tile1 - a.tile0;
@@ -490,17 +492,42 @@ static int launch_wgrad16_t(afx_ctx* c, const WgradArgs& w, const ReduceArgs& rd
   return AFX_OK;
 }
 
+// 8-bit stash (f16 mode, rays, no encoding): k_wgrad_s8 + the group-sum reduction
+template <int F>
+static int launch_wgrad8_t(afx_ctx* c, const WgradArgs& w, const ReduceArgs& rd, int N, hipStream_t st) {
+  {
+    const size_t lds = (size_t)4 * (2 * (F / 16) * (64 * 16 + 128) + 64 * 4);      // 4-stage ring of (J + H image, dL/draw)
+    if (!c->attr_done.count((const void*)k_wgrad_s8<F>)) {
+      HIPCHK(hipFuncSetAttribute((const void*)k_wgrad_s8<F>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      c->attr_done.insert((const void*)k_wgrad_s8<F>);
+    }
+    ProfScope ps(c, AFX_K_WGRAD, st);
+    hipLaunchKernelGGL(k_wgrad_s8<F>, dim3(w.n_splits, N), dim3(512), lds, st, w);
+  }
+  hipLaunchKernelGGL(k_small_from_groups<F>, dim3(rd.n_small), dim3(F), 0, st, w);
+  hipLaunchKernelGGL(k_reduce_w<F>, dim3((F * F + 255) / 256, N + 1), dim3(256), 0, st, rd);
+  hipLaunchKernelGGL(k_reduce_b<F>, dim3(1, N + 2), dim3(F), 0, st, rd);
+  hipLaunchKernelGGL(k_reduce_small<F>, dim3((unsigned)((F * rd.k0pad + 2 * F + 1 + 63) / 64)), dim3(64, 4), 0, st, rd);
+  HIPCHK(hipGetLastError());
+  return AFX_OK;
+}
+
 // Shared by afx_render_backward / afx_mlp_backward: chain (recompute + input-gradient chain +
 // stash) then the weight-gradient contraction, chunk by chunk.  `a` is fully filled except the
 // backward pointers; `head` bytes at the start of the workspace are already in use (dod).
 static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws, size_t ws_bytes, float* grad_flat, hipStream_t st) {
   const int F = c->d.width, N = c->d.n_hidden;
-  const BwdLayout B = bwd_layout(c, prec, 0);
+  BwdLayout B = bwd_layout(c, prec, 0);
   const size_t fixed = head + B.fixed_bytes;
   const int TILE = bwd_tile(prec);
   const bool b16 = is_bf16(prec);
-  const size_t esz = b16 ? 2 : 4;                       // stash element size
+  // in-kernel small gradients: 8-wave 16-bit backward kernel, rays, raw coordinates as inputs (AFX_SMALL_IN_KERNEL=0: off)
+  const bool sg = b16 && a.mode == 1 && c->d.enc == AFX_ENC_NONE && c->small_in_kernel;
+  const bool s8 = prec == AFX_PREC_F16S8 && sg;          // 8-bit stash: that configuration only; otherwise the 16-bit f16 path
+  const size_t esz = s8 ? 1 : (b16 ? 2 : 4);            // stash element size
   const int k0ld = b16 ? 16 * nk0_of(c) : c->k0pad;     // row length of the encoded-input stash
+  if (is_bf16(prec) && prec == AFX_PREC_F16S8 && a.mode == 1 && c->d.enc == AFX_ENC_NONE && c->small_in_kernel)
+    B.per_tile_bytes = (size_t)256 * (2 * ((size_t)c->d.n_hidden + 1) * c->d.width + 4 * 16 * nk0_of(c) + 4);     // 1 byte per stash element
   if (ws_bytes < fixed + B.per_tile_bytes + 1024) return fail(AFX_E_WORKSPACE, "backward workspace %zu too small (min %zu)", ws_bytes, fixed + 32 * B.per_tile_bytes);
   const int64_t tiles = (a.n_total + TILE - 1) / TILE;
   int64_t chunk = (int64_t)((ws_bytes - fixed - 1024) / B.per_tile_bytes);      // 1 KiB slack for buffer alignment
@@ -524,7 +551,7 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
   float* partial_s = (float*)(ws + off);
   if (b16) off += rup64((size_t)kSmallBlocks * (F * k0ld + 2 * F + 4) * 4, 256);
   uint32_t* gmax_words = (uint32_t*)(ws + off); off += 256;
-  const bool h16 = prec == AFX_PREC_F16;
+  const bool h16 = is_f16(prec);
   const size_t rows = (size_t)chunk * TILE;
   float *stash_h[2], *stash_dz[2], *stash_e[2], *graw[2];
   for (int bI = 0; bI < nbuf; ++bI) {
@@ -536,7 +563,7 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
   a.stash_rows = (int64_t)rows;
   a.debug = 0;
   // in-kernel small gradients: 8-wave bf16 backward kernel, rays, raw coordinates as inputs (AFX_SMALL_IN_KERNEL=0: off)
-  const bool sg = b16 && a.mode == 1 && c->d.enc == AFX_ENC_NONE && c->small_in_kernel;
+  a.stash8 = s8 ? 1 : 0;
   a.persistent = (nbuf == 2 && !c->persistent_chain) ? 0 : 1;
   int64_t ci = 0;
   for (int64_t t0 = 0; t0 < tiles; t0 += chunk, ++ci) {
@@ -571,13 +598,14 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
     rps = (rps + 63) / 64 * 64;        // whole 32-/64-sample stages
     w.rows_per_split = (int)rps;
     w.partial = partial; w.partial2 = partial2; w.partial_s = partial_s; w.debug = a.debug; w.small_groups = sg ? 1 : 0;
-    w.gmax = a.gmax;
+    w.gmax = a.gmax; w.stash_esz = (int)esz; w.wout_perm = a.small + (size_t)(N + 1) * F;
     ReduceArgs rd;
     rd.partial = partial; rd.partial2 = partial2; rd.n_hidden = N; rd.k0 = c->k0; rd.k0pad = k0ld; rd.n_splits = splits;
     rd.grad = grad_flat; rd.hidden_only = b16 ? 1 : 0; rd.partial_s = partial_s;
     rd.n_small = kSmallBlocks;      // records; every record is written (possibly with zero rows)
-    rd.gmax = a.gmax;
+    rd.gmax = a.gmax; rd.scale_shift = s8 ? AFX_S8_JSHIFT : 0;
     if (!b16) rc = F == 64 ? launch_wgrad_t<64>(c, w, rd, N, ws_st) : (F == 128 ? launch_wgrad_t<128>(c, w, rd, N, ws_st) : launch_wgrad_t<256>(c, w, rd, N, ws_st));
+    else if (s8) rc = F == 64 ? launch_wgrad8_t<64>(c, w, rd, N, ws_st) : (F == 128 ? launch_wgrad8_t<128>(c, w, rd, N, ws_st) : launch_wgrad8_t<256>(c, w, rd, N, ws_st));
     else if (h16) rc = F == 64 ? launch_wgrad16_t<64, true>(c, w, rd, N, ws_st) : (F == 128 ? launch_wgrad16_t<128, true>(c, w, rd, N, ws_st) : launch_wgrad16_t<256, true>(c, w, rd, N, ws_st));
     else rc = F == 64 ? launch_wgrad16_t<64, false>(c, w, rd, N, ws_st) : (F == 128 ? launch_wgrad16_t<128, false>(c, w, rd, N, ws_st) : launch_wgrad16_t<256, false>(c, w, rd, N, ws_st));
     if (rc) return rc;

@@ -1,22 +1,23 @@
 // afx_inst.h — the instantiation list of the 16-bit chain kernels, shared by the translation units that define them
 // (afx_inst_chain16.hip, compiled once per width and direction, in parallel) and the host code that launches them.
-// X(F, X3, ENC, BWD, NW, SG, H16)
+// X(F, X3, ENC, BWD, NW, SG, H16, S8)
 #pragma once
 #define AFX_CHAIN16_FWD(X, F)          \
-  X(F, true, false, false, 4, false, false)  \
-  X(F, true, true, false, 4, false, false)   \
-  X(F, false, false, false, 8, false, false) \
-  X(F, false, true, false, 8, false, false)  \
-  X(F, false, false, false, 8, false, true)  \
-  X(F, false, true, false, 8, false, true)
+  X(F, true, false, false, 4, false, false, false)  \
+  X(F, true, true, false, 4, false, false, false)   \
+  X(F, false, false, false, 8, false, false, false) \
+  X(F, false, true, false, 8, false, false, false)  \
+  X(F, false, false, false, 8, false, true, false)  \
+  X(F, false, true, false, 8, false, true, false)
 #define AFX_CHAIN16_BWD(X, F)          \
-  X(F, false, false, true, 8, false, false)  \
-  X(F, false, true, true, 8, false, false)   \
-  X(F, false, false, true, 8, true, false)   \
-  X(F, false, false, true, 8, false, true)   \
-  X(F, false, true, true, 8, false, true)    \
-  X(F, false, false, true, 8, true, true)
-#define AFX_CHAIN16_DECL(F, X3, ENC, BWD, NW, SG, H16) \
-  extern template __global__ void k_chain_bf16<F, X3, ENC, BWD, NW, SG, H16>(const afx::ChainArgs);
-#define AFX_CHAIN16_DEF(F, X3, ENC, BWD, NW, SG, H16) \
-  template __global__ void k_chain_bf16<F, X3, ENC, BWD, NW, SG, H16>(const afx::ChainArgs);
+  X(F, false, false, true, 8, false, false, false)  \
+  X(F, false, true, true, 8, false, false, false)   \
+  X(F, false, false, true, 8, true, false, false)   \
+  X(F, false, false, true, 8, false, true, false)   \
+  X(F, false, true, true, 8, false, true, false)    \
+  X(F, false, false, true, 8, true, true, false)    \
+  X(F, false, false, true, 8, true, true, true)
+#define AFX_CHAIN16_DECL(F, X3, ENC, BWD, NW, SG, H16, S8) \
+  extern template __global__ void k_chain_bf16<F, X3, ENC, BWD, NW, SG, H16, S8>(const afx::ChainArgs);
+#define AFX_CHAIN16_DEF(F, X3, ENC, BWD, NW, SG, H16, S8) \
+  template __global__ void k_chain_bf16<F, X3, ENC, BWD, NW, SG, H16, S8>(const afx::ChainArgs);

@@ -73,6 +73,7 @@ struct ChainArgs {
   // in-kernel small gradients (bf16 backward, rays mode, no encoding): per 32-sample group [SW[F] S0[F] S1[F] c[3] d[3] sum_g -]
   float* small_part;        // null: H_N, dZ_0, encoded inputs and dL/draw are stashed for k_small_grads_bf16 instead
   uint32_t* gmax;           // f16 mode: bit pattern of max |dL/draw| over the chunk (integer atomicMax; zeroed per chunk)
+  int32_t stash8;           // f16 mode: 8-bit (bf8) stash of H_l and J_l
 };
 
 struct WgradArgs {
@@ -90,6 +91,8 @@ struct WgradArgs {
   float* partial_s;         // bf16 path: [n_small, F*k0pad + 2F + 4] first-layer / output-layer partials
   int32_t small_groups;     // 1: the chain kernel left per-group sums where H_N's stash would be (k_small_from_groups)
   const uint32_t* gmax;     // f16 mode: the chunk's max |dL/draw| (scale of the contraction, wgrad_scale_exp)
+  int32_t stash_esz;        // bytes per stash element (4 f32, 2 bf16/f16, 1 bf8)
+  const float* wout_perm;   // 8-bit stash: permuted output weights in the prepared `small` section (layer-N row fix)
 };
 
 struct ReduceArgs {
@@ -101,6 +104,7 @@ struct ReduceArgs {
   const float* partial_s;
   float* grad;              // flat parameter gradient, accumulated into
   const uint32_t* gmax;     // f16 mode: hidden-layer partials carry the factor 2^-e (wgrad_scale_exp); null otherwise
+  int32_t scale_shift;      // 8-bit stash: and the factor 2^scale_shift of the stashed J
 };
 
 }  // namespace afx

@@ -23,6 +23,7 @@
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
@@ -73,6 +74,34 @@ template <int F> __device__ __forceinline__ uint32_t stash_off(uint32_t r, int c
   return ((((r >> 5) * (F / 8) + ch) << 5) + (r & 31)) << 4;      // < 2^32: the host bounds a layer's stash
 }
 
+// S8 (8-bit stash, f16 mode): H_l and J_l are stashed as bf8 (e5m2: the top byte of the f16 pattern, same exponent
+// range, so H needs no scale; J is scaled by 2^AFX_S8_JSHIFT, its values sit around 1e-4..1).  A lane's 16 values of a
+// tile are ONE 16-byte store: stash position p8 = 16 (2t + h) + 8 s + j for feature 32t + 16s + 8(j>>2) + 4h + (j&3);
+// layout [row>>5][p8>>4][row&31][16 B], so a wave store is again one contiguous 1 KiB run.  Half the bytes of the
+// 16-bit stash in both directions.
+#define AFX_S8_JSHIFT 10
+template <int F> __device__ __forceinline__ uint32_t stash_off8(uint32_t r, int ch16) {
+  return ((((r >> 5) * (F / 16) + ch16) << 5) + (r & 31)) << 4;
+}
+// 8 packed f16 pairs (16 values, stash order) -> 16 bf8 bytes; value / scale is what is stored
+__device__ __forceinline__ u32x4 to_bf8x16(u32x4 a, u32x4 b, float scale) {
+  u32x4 r;
+  const unsigned src[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    s16x2 v = {0, 0};
+    v = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(v, __builtin_bit_cast(f16x2_t, src[2 * i]), scale, false);
+    v = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(v, __builtin_bit_cast(f16x2_t, src[2 * i + 1]), scale, true);
+    r[i] = __builtin_bit_cast(unsigned, v);
+  }
+  return r;
+}
+// stash position -> feature for the 8-bit layout (a permutation inside each block of 32)
+__device__ __forceinline__ int fperm8(int p) {
+  const int hh = (p >> 4) & 1, s2 = (p >> 3) & 1, j = p & 7;
+  return (p & ~31) | (s2 << 4) | ((j >> 2) << 3) | (hh << 2) | (j & 3);
+}
+
 // 16-byte stash store, non-temporal: the stash is written once and read once by another kernel, so it must not
 // displace the weight slabs every workgroup re-streams from L2.  A/B in one process on the 512^2x128 step,
 // k_chain<bwd>: plain 116 ms, nt 99 ms, sc1 (write-through) 121 ms.
@@ -81,7 +110,6 @@ __device__ __forceinline__ void stash_store(char* p, u32x4 v) { __builtin_nontem
 // Packed-bf16 epilogue helpers.  The bf16 sign bit is the int16 sign bit, so ReLU of two packed values is
 // one v_pk_max_i16, [h != 0] per half one v_pk_min_u16, and a per-half 0xffff/0 mask from bit q of each
 // half is v_pk_lshlrev_b16 + v_pk_ashrrev_i16: half the VALU work of the same operations on fp32 values.
-typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned relu2(unsigned p) {
   return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p), (s16x2){0, 0}));
@@ -141,8 +169,9 @@ template <int K> __device__ __forceinline__ void lds_wait_frag(u32x4& r) {
 // (dW_out += SW, db_0 += S0, dW_0 += S0 c^T + S1 d^T; k_small_from_groups).  The sums run over the LANE dimension
 // of the fragments; an MFMA against a 0/1 selection matrix transposes a fragment exactly (bf16 x 1.0, fp32
 // accumulate) into the C layout - lane = feature position, 16 registers = samples - where the sum is 16 VALU FMAs.
-template <int F, bool X3, bool ENC, bool BWD, int NW, bool SG = false, bool H16 = false>
+template <int F, bool X3, bool ENC, bool BWD, int NW, bool SG = false, bool H16 = false, bool S8 = false>
 __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs a) {
+  static_assert(!S8 || (SG && H16), "8-bit stash: f16 backward kernel with in-kernel small gradients");
   static_assert(!SG || (BWD && !ENC && !X3), "in-kernel small gradients: plain backward kernel without encoding");
   static_assert(!(H16 && (X3 || NW != 8)), "f16 hidden layers: 8-wave kernels only");
   static_assert(!(X3 && BWD), "the backward chain runs in plain bf16");
@@ -176,7 +205,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
   constexpr uint32_t STEP0 = TPS * SLAB0, STEPH = TPS * SLABT;        // bytes one step streams (X3: STEPH hi + STEPH lo)
   constexpr uint32_t SLOT = chain_slot_bytes(NT, NK0, BWD, X3);
   constexpr int PIECES0 = STEP0 / (NW * 1024u), PIECESH = STEPH / (NW * 1024u);      // LDS-DMA instructions per wave and step
-  constexpr int SPS = 2 * NCG * TPS;                                  // stash stores per wave and step (backward kernel)
+  constexpr int SPS = (S8 ? 1 : 2) * NCG * TPS;                       // stash stores per wave and step (backward kernel)
 
   char* slot0 = lds + a.small_bytes_pad;
   // The prepared buffer holds [first-layer slabs | forward hidden slabs (hi) | transposed slabs] as ONE contiguous
@@ -268,7 +297,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
     for (int cg = 0; cg < NCG; ++cg) {
       n[cg] = tile * TS + wave * (32 * NCG) + cg * 32 + col;
       m[cg] = (uint32_t)(tile - a.tile0) * TS + wave * (32 * NCG) + cg * 32 + col;
-      so[cg] = stash_off<F>(m[cg], hh);
+      so[cg] = S8 ? stash_off8<F>(m[cg], hh) : stash_off<F>(m[cg], hh);
       sp[cg] = make_sample(a, n[cg]);
       // first-layer B fragments: element j of k-step q is encoded input k = 16q + 8*(lane>>5) + j
 #pragma unroll
@@ -337,12 +366,17 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           nf[s] = (u32x4){p[4 * s], p[4 * s + 1], p[4 * s + 2], p[4 * s + 3]};
+          if (S8) continue;
           if (BWD && !(SG && l == N)) {
             // stash position of feature 32t+16s+8(j>>2)+4h+(j&3) is p = 32t+16s+8h+j (bits 2,3 swapped; the
             // weight-gradient kernels undo it with fperm).  Layout [row>>5][p>>3][row&31][8 bf16]: the 64 lanes
             // of this store write one contiguous 1 KiB run (32 samples x 16 B for h = 0, then for h = 1).
             stash_store((char*)a.stash_h + (size_t)l * a.stash_rows * (F * 2) + (so[cg] + (uint32_t)(4 * t + 2 * s) * 512u), nf[s]);
           }
+        }
+        if constexpr (S8) {
+          if (l != N)       // one 16-byte store per tile: chunk 2t + h of the 8-bit layout
+            stash_store((char*)a.stash_h + (size_t)l * a.stash_rows * F + (so[cg] + (uint32_t)(2 * t) * 512u), to_bf8x16(nf[0], nf[1], 1.0f));
         }
         // the reloaded bias is waited for HERE (it has long landed), not by an lgkmcnt(0) behind the next tile's first
         // fragment reads, which would expose their round trip at every tile start
@@ -632,10 +666,16 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
       auto mma_step_plain = [&](const u32x4* sl, u32x4 (*bh)[NT][2], f32x16* acc) { rolling_mma_impl(std::integral_constant<int, AFX_PF_BWD>{}, sl, bh, acc); };
       auto stash_dz_tile = [&](int l, int t) {
 #pragma unroll
-        for (int cg = 0; cg < NCG; ++cg)
+        for (int cg = 0; cg < NCG; ++cg) {
+          if constexpr (S8) {
+            stash_store((char*)a.stash_dz + (size_t)l * a.stash_rows * F + (so[cg] + (uint32_t)(2 * t) * 512u),
+                        to_bf8x16(dz[cg][t][0], dz[cg][t][1], 1.0f / (float)(1 << AFX_S8_JSHIFT)));
+          } else {
 #pragma unroll
-          for (int s = 0; s < 2; ++s)
-            stash_store((char*)a.stash_dz + (size_t)l * a.stash_rows * (F * 2) + (so[cg] + (uint32_t)(4 * t + 2 * s) * 512u), dz[cg][t][s]);
+            for (int s = 0; s < 2; ++s)
+              stash_store((char*)a.stash_dz + (size_t)l * a.stash_rows * (F * 2) + (so[cg] + (uint32_t)(4 * t + 2 * s) * 512u), dz[cg][t][s]);
+          }
+        }
       };
       for (int l = N; l >= 1; --l) {
         u32x4 dn[NCG][NT][2];
@@ -723,6 +763,9 @@ __device__ __forceinline__ int fperm(int p) { return (p & ~12) | ((p & 4) << 1) 
 //   dW_l Ls = sum_n J_l[n][o] * (g_n Ls) H_{l-1}[n][i]   on v_mfma_f32_32x32x16_f16,
 // scaling the B fragments by packed (g Ls) pairs (one v_pk_mul_f16 per dword; the pairs are the same for all lanes of a
 // half-wave, a broadcast LDS read).  Ls = 2^-e from the chunk's max |g| (wgrad_scale_exp); the reduce kernels undo it.
+__device__ __forceinline__ void lds_tr16(s16x4& dst, uint32_t addr, int imm) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm) : "memory");
+}
 template <int F, bool H16 = false>
 __global__ void __launch_bounds__(512) k_wgrad_bf16(const WgradArgs a) {
   constexpr int NT = F / 32;
@@ -737,7 +780,10 @@ __global__ void __launch_bounds__(512) k_wgrad_bf16(const WgradArgs a) {
   constexpr int GOFF = 4 * IMG;              // H16: behind the two stages, per stage [64 x f16 (g Ls) | 64 x f32 (g Ls)]
   constexpr int GST = KB * 2 + KB * 4;
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, hh = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, col = lane & 31, hh = lane >> 5;
+  // provably wave-uniform: `if (i == wc)` around an MFMA must be a SCALAR branch - MFMA ignores EXEC, so under an
+  // exec-masked "branch" all four candidates would execute
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int layer = blockIdx.y + 1, split = blockIdx.x;
   float ls = 1.f;
   if constexpr (H16) ls = ldexpf(1.f, -wgrad_scale_exp(a.gmax));
@@ -755,7 +801,6 @@ __global__ void __launch_bounds__(512) k_wgrad_bf16(const WgradArgs a) {
   for (int i = 0; i < TR; ++i)
 #pragma unroll
     for (int j = 0; j < TC; ++j) acc[i][j] = (f32x16){0.f};
-  float bsum = 0.f;
 
   // one LDS-DMA instruction per chunk column: lane = stage row; source = two contiguous 512-byte runs
   auto stage_load = [&](int st, int buf) {
@@ -777,16 +822,18 @@ __global__ void __launch_bounds__(512) k_wgrad_bf16(const WgradArgs a) {
     const int c = fb0 + 16 * (g4 & 1) + 4 * tp;
     return (c >> 3) * CS + row * 16 + 8 * (tp & 1);
   };
-  auto tr_frag = [&](const char* img, int ks, int fb0) -> u32x4 {
-    const s16x4 x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + tr_off(ks, 0, fb0)));
-    const s16x4 y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + tr_off(ks, 1, fb0)));
-    const s16x8 f = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
-    return __builtin_bit_cast(u32x4, f);
-  };
-
   // H16: g of the stage's 64 samples: loaded by the first wave with the stage's DMA, written to LDS once it has landed
   float greg = 0.f;
   auto g_load = [&](int st) { if (H16 && tid < KB) greg = a.graw[r0 + (int64_t)st * KB + tid]; };
+  // Every LDS read of the loop is inline asm (see k_wgrad_s8: hipcc otherwise drains ALL outstanding LDS-DMA with
+  // s_waitcnt vmcnt(0) in front of the first read, i.e. the next stage's DMA never overlapped this stage's MFMAs);
+  // bias gradients come out of the matrix pipe: B = the (g Ls) fragment (H16) or a fragment of ones (bf16).
+  const uint32_t lbase = (uint32_t)(uintptr_t)LPTR(lds);
+  // lane part of a transposed read's address (tr_off) + the operand's first 32-position tile; the rest is an immediate
+  const uint32_t lpart = (uint32_t)(((16 * (g4 & 1) + 4 * tp) >> 3) * CS + (8 * (g4 >> 1) + tq) * 16 + 8 * (tp & 1));
+  const uint32_t offA = lpart + (uint32_t)(4 * wr * TR * CS), offB = lpart + (uint32_t)(IMG + 4 * wc * TC * CS);
+  const bool has_bias = active && wc < TR;
+  f32x16 accb = (f32x16){0.f};
   if (nst > 0) { stage_load(0, 0); g_load(0); }
   for (int st = 0; st < nst; ++st) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -794,43 +841,42 @@ __global__ void __launch_bounds__(512) k_wgrad_bf16(const WgradArgs a) {
       const float gs = greg * ls;
       char* gb = lds + GOFF + (st & 1) * GST;
       *(_Float16*)(gb + tid * 2) = (_Float16)gs;
-      *(float*)(gb + KB * 2 + tid * 4) = gs;
     }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (st + 1 < nst) { stage_load(st + 1, (st + 1) & 1); g_load(st + 1); }
-    const char* sA = lds + (st & 1) * 2 * IMG;
-    const char* sB = sA + IMG;
-    const char* sG = lds + GOFF + (st & 1) * GST;
     if (active) {
+      const uint32_t sA = lbase + (uint32_t)((st & 1) * 2 * IMG);
+      const uint32_t sG = lbase + (uint32_t)(GOFF + (st & 1) * GST + 16 * hh);
 #pragma unroll
       for (int ks = 0; ks < KB / 16; ++ks) {
-        u32x4 af[TR], bf[TC];
-#pragma unroll
-        for (int i = 0; i < TR; ++i) af[i] = tr_frag(sA, ks, 32 * (wr * TR + i));
-#pragma unroll
-        for (int j = 0; j < TC; ++j) bf[j] = tr_frag(sB, ks, 32 * (wc * TC + j));
-        if constexpr (H16) {
-          // element j of a fragment is stage row 16 ks + 8 hh + j: four packed (g Ls) pairs, the same for the whole half-wave
-          // (whole-vector multiply: element-wise writes through bf[j][q] were miscompiled by hipcc 7.2 into a chain on element 0)
-          const f16x8_t gp = *(const f16x8_t*)(sG + (ks * 16 + 8 * hh) * 2);
-#pragma unroll
-          for (int j = 0; j < TC; ++j) bf[j] = __builtin_bit_cast(u32x4, __builtin_bit_cast(f16x8_t, bf[j]) * gp);
-        }
+        s16x4 ax[TR][2], bx[TC][2];
+        u32x4 gpk = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};       // bf16 ones
 #pragma unroll
         for (int i = 0; i < TR; ++i)
 #pragma unroll
+          for (int rd = 0; rd < 2; ++rd) lds_tr16(ax[i][rd], sA + offA, 4 * i * CS + ks * 256 + rd * 64);
+#pragma unroll
+        for (int j = 0; j < TC; ++j)
+#pragma unroll
+          for (int rd = 0; rd < 2; ++rd) lds_tr16(bx[j][rd], sA + offB, 4 * j * CS + ks * 256 + rd * 64);
+        if constexpr (H16) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(gpk) : "v"(sG), "n"(ks * 32) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        u32x4 af[TR], bf[TC];
+#pragma unroll
+        for (int i = 0; i < TR; ++i) af[i] = __builtin_bit_cast(u32x4, (s16x8){ax[i][0][0], ax[i][0][1], ax[i][0][2], ax[i][0][3], ax[i][1][0], ax[i][1][1], ax[i][1][2], ax[i][1][3]});
+#pragma unroll
+        for (int j = 0; j < TC; ++j) {
+          bf[j] = __builtin_bit_cast(u32x4, (s16x8){bx[j][0][0], bx[j][0][1], bx[j][0][2], bx[j][0][3], bx[j][1][0], bx[j][1][1], bx[j][1][2], bx[j][1][3]});
+          // H16: element j of a fragment is stage row 16 ks + 8 hh + j: four packed (g Ls) pairs, the same for the whole half-wave
+          // (whole-vector multiply: element-wise writes through bf[j][q] were miscompiled by hipcc 7.2 into a chain on element 0)
+          if constexpr (H16) bf[j] = __builtin_bit_cast(u32x4, __builtin_bit_cast(f16x8_t, bf[j]) * __builtin_bit_cast(f16x8_t, gpk));
+        }
+#pragma unroll
+        for (int i = 0; i < TR; ++i) {
+#pragma unroll
           for (int j = 0; j < TC; ++j) acc[i][j] = mfma_t<H16>(af[i], bf[j], acc[i][j]);
-      }
-    }
-    // bias gradient: column sums of the dZ image on the VALU (512 threads: F positions x 512/F row groups); H16: sum_n (g_n Ls) J
-    {
-      const int f = tid % F, part = tid / F;
-      constexpr int PARTS = 512 / F;
-#pragma unroll 8
-      for (int r = part; r < KB; r += PARTS) {
-        const unsigned short v = *(const unsigned short*)(sA + (f >> 3) * CS + r * 16 + (f & 7) * 2);
-        if constexpr (H16) bsum = fmaf(*(const float*)(sG + KB * 2 + r * 4), (float)__builtin_bit_cast(_Float16, v), bsum);
-        else bsum += __builtin_bit_cast(float, (unsigned)v << 16);
+          if (i == wc) accb = mfma_t<H16>(af[i], gpk, accb);
+        }
       }
     }
   }
@@ -844,14 +890,197 @@ __global__ void __launch_bounds__(512) k_wgrad_bf16(const WgradArgs a) {
         for (int r = 0; r < 16; ++r)
           P[(size_t)fperm(32 * (wr * TR + i) + rowperm(r) + 4 * hh) * F + fperm(32 * (wc * TC + j) + col)] = acc[i][j][r];
   }
-  __syncthreads();
-  float* red = (float*)lds;
-  red[tid] = bsum;
-  __syncthreads();
-  if (tid < F) {
-    float s = 0.f;
-    for (int q = 0; q < 512 / F; ++q) s += red[q * F + tid];
-    a.partial2[((size_t)layer * a.n_splits + split) * (F + 4) + fperm(tid)] = s;
+  if (has_bias && col == 0) {        // every column of accb holds the row sums
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      a.partial2[((size_t)layer * a.n_splits + split) * (F + 4) + fperm(32 * (wr * TR + wc) + rowperm(r) + 4 * hh)] = accb[r];
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Weight gradients from the 8-bit stash (f16 mode, S8): H_{l-1} and J_l 2^AFX_S8_JSHIFT as bf8, layout
+// [row>>5][p8>>4][row&31][16 B].  Same contraction as k_wgrad_bf16<F, true>:
+//   dW_l Ls 2^JSHIFT = sum_n (J_l[n][o] 2^JSHIFT) * (g_n Ls) H_{l-1}[n][i]
+// A 64-sample stage is 2 x F/16 LDS-DMA instructions (lane = stage row, 16 bytes); one ds_read_b64_tr_b8 delivers
+// the 8 samples x 1 position an MFMA operand lane needs as 8 bytes (lane 2q+p of a 16-lane group supplies row q,
+// bytes 8p..8p+7 of a 16-byte chunk; lane i receives byte i of the 8 rows), four v_cvt_scalef32_pk_f16_bf8 turn them
+// into the f16 fragment.  Chunk columns are padded to 1152 B: the two 16-lane groups of a half-wave read 128
+// contiguous bytes each, 32 banks apart.
+// Layer N: J_N = w_out * [H_N > 0] has one value per feature, whose bf8 rounding would be a SYSTEMATIC error of the
+// row; every non-zero byte decodes to the same number, so the A fragment (lane = feature) is rescaled by the per-lane
+// constant f16(w_out) 2^JSHIFT / decoded value, which restores f16(w_out) exactly where the mask is set.
+// ---------------------------------------------------------------------------------------
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32x4 bf8x8_to_f16(i32x2 x) {
+  u32x4 r;
+  r[0] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_f16_bf8((unsigned)x[0], 1.0f, false));
+  r[1] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_f16_bf8((unsigned)x[0], 1.0f, true));
+  r[2] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_f16_bf8((unsigned)x[1], 1.0f, false));
+  r[3] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_f16_bf8((unsigned)x[1], 1.0f, true));
+  return r;
+}
+// w_out of feature f from the permuted copy in the prepared `small` section ([(h*NT + t)*16 + j], row = 32t + R(j) + 4h)
+__device__ __forceinline__ float wout_of(const float* wout_perm, int NT, int f) {
+  const int t = f >> 5, w = f & 31, h = (w >> 2) & 1, j = (w & 3) + 4 * (w >> 3);
+  return wout_perm[(h * NT + t) * 16 + j];
+}
+// ratio that restores f16(w_out) from its stashed bf8 image (0 when the image underflowed to 0)
+__device__ __forceinline__ float s8_wout_fix(float w) {
+  const _Float16 wh = (_Float16)w;
+  s16x2 v = {0, 0};
+  v = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(v, (f16x2_t){wh, wh}, 1.0f / (float)(1 << AFX_S8_JSHIFT), false);
+  const float dec = (float)__builtin_amdgcn_cvt_scalef32_pk_f16_bf8(__builtin_bit_cast(unsigned, v), 1.0f, false)[0];
+  return dec != 0.f ? (float)wh * (float)(1 << AFX_S8_JSHIFT) / dec : 0.f;
+}
+
+// Pipeline: a ring of NS = 4 stages in LDS (the 8-bit stage is 36 KiB), NS-1 stages of LDS-DMA in flight per workgroup
+// (~100 KB per CU: enough to cover the HBM latency at full bandwidth; with one stage in flight the kernel ran at the
+// DMA round trip per stage, 2.6 TB/s).  One barrier per stage; every wave waits for its OWN DMA instructions of the
+// stage with a counted vmcnt (they complete in order), the barrier then covers the other waves' pieces.  dL/draw of the
+// stage's rows rides along as a 256-byte DMA by wave 0.
+// Every LDS read of the loop is inline asm: hipcc orders a plain LDS load (and the ds_read_tr builtins) behind ALL
+// outstanding LDS-DMA with an s_waitcnt vmcnt(0), which would put the whole DMA round trip back in front of every stage.
+// Bias gradients come out of the matrix pipe as well: the B fragment whose 8 elements are (g Ls) of the 8 rows is the
+// same for all 32 columns, so one extra MFMA per k-step and wave gives sum_n (g_n Ls) J[n][o] for a 32-row tile.
+__device__ __forceinline__ void lds_tr8(i32x2& dst, uint32_t addr, int imm) {
+  asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm) : "memory");
+}
+__device__ __forceinline__ void lds_rd128f(f32x4& dst, uint32_t addr, int imm) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm) : "memory");
+}
+
+template <int F>
+__global__ void __launch_bounds__(512) k_wgrad_s8(const WgradArgs a) {
+  constexpr int NT = F / 32;
+  constexpr int TR = NT >= 2 ? NT / 2 : 1, WR = NT / TR;
+  constexpr int TC = NT >= 4 ? NT / 4 : 1, WC = NT / TC;
+  constexpr int KB = 64;
+  constexpr int NCH = F / 16;                // 16-byte chunk columns per stash row
+  constexpr int CS = KB * 16 + 128;
+  constexpr int IMG = NCH * CS;
+  constexpr int NS = 4;                      // ring depth
+  constexpr int GOFF = NS * 2 * IMG;         // per stage: 64 x f32 dL/draw
+  constexpr int PER = 2 * ((NCH + 7) / 8);   // LDS-DMA instructions per wave and stage (waves beyond NCH: none, their waits are no-ops)
+  static_assert(2 * (NT - 1) * CS + 3 * 256 + 1151 < 65536 && IMG < 65536, "ds offset immediates are 16 bits");
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, col = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int layer = blockIdx.y + 1, split = blockIdx.x;
+  const float ls = ldexpf(1.f, -wgrad_scale_exp(a.gmax));
+  const char* A = (const char*)a.stash_dz + (size_t)layer * a.stride_rows * F;
+  const char* B = (const char*)a.stash_h + (size_t)(layer - 1) * a.stride_rows * F;
+  int64_t r0 = (int64_t)split * a.rows_per_split;
+  int64_t r1 = r0 + a.rows_per_split;
+  if (r1 > a.rows) r1 = a.rows;
+  const int nst = r1 > r0 ? (int)((r1 - r0) / KB) : 0;
+  const bool active = wave < WR * WC;
+  const int wr = wave / WC, wc = wave % WC;
+  const bool lastl = layer == a.n_hidden;
+  const bool has_bias = active && wc < TR;   // this wave also sums the bias gradient of its row tile wc
+
+  f32x16 acc[TR][TC], accb = (f32x16){0.f};
+#pragma unroll
+  for (int i = 0; i < TR; ++i)
+#pragma unroll
+    for (int j = 0; j < TC; ++j) acc[i][j] = (f32x16){0.f};
+  // layer N: per-lane correction of the A rows this wave owns (lane&31 = row of the 32-position tile)
+  f16x8_t afix[TR];
+#pragma unroll
+  for (int i = 0; i < TR; ++i) {
+    const _Float16 r = (_Float16)(lastl ? s8_wout_fix(wout_of(a.wout_perm, NT, fperm8(32 * (wr * TR + i) + col))) : 1.f);
+    afix[i] = (f16x8_t){r, r, r, r, r, r, r, r};
+  }
+
+  auto stage_load = [&](int st) {
+    const int buf = st % NS;
+    char* dA = lds + buf * 2 * IMG;
+    char* dB = dA + IMG;
+    const int64_t g0 = (r0 + (int64_t)st * KB) >> 5;
+    for (int c = wave; c < NCH; c += 8) {
+      const size_t src = ((((size_t)(g0 + hh) * NCH + c) << 5) + col) << 4;
+      __builtin_amdgcn_global_load_lds(GPTR(A + src), LPTR(dA + c * CS), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GPTR(B + src), LPTR(dB + c * CS), 16, 0, 0);
+    }
+    if (wave == 0) __builtin_amdgcn_global_load_lds(GPTR(a.graw + r0 + (int64_t)st * KB + lane), LPTR(lds + GOFF + buf * (KB * 4)), 4, 0, 0);
+  };
+  const int g4 = lane >> 4, li = lane & 15;
+  // lane 2q+p of a 16-lane group: row q of the 8-row block, bytes 8p..8p+7 of chunk 2T + (g4&1)
+  const uint32_t lbase = (uint32_t)(uintptr_t)LPTR(lds);
+  const uint32_t troff = (uint32_t)((g4 & 1) * CS + (8 * (g4 >> 1) + (li >> 1)) * 16 + 8 * (li & 1));
+  const uint32_t offA = troff + (uint32_t)(2 * wr * TR * CS), offB = troff + (uint32_t)(IMG + 2 * wc * TC * CS);
+
+#pragma unroll
+  for (int i = 0; i < NS - 1; ++i)
+    if (i < nst) stage_load(i);
+  for (int st = 0; st < nst; ++st) {
+    // stage st has landed once this wave's younger (NS-2 stages of) DMA instructions are all that is outstanding
+#ifdef AFX_SAFE_WAITS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+    if (st + NS - 2 < nst) {
+      if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NS - 2) * (PER + 1)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NS - 2) * PER) : "memory");
+    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the last stages: fewer younger ones to count on
+#endif
+    // raw barrier (__syncthreads() would drain vmcnt): every wave's pieces of stage st are in LDS, and every wave is done
+    // reading stage st-1 (its LDS reads have returned: lgkmcnt(0)), whose slot the next request overwrites
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (st + NS - 1 < nst) stage_load(st + NS - 1);
+    if (active) {
+      const uint32_t sbase = lbase + (uint32_t)((st % NS) * 2 * IMG);
+      const uint32_t gbase = lbase + (uint32_t)(GOFF + (st % NS) * (KB * 4) + 32 * hh);
+      // the reads of k-step ks+1 are issued before the MFMAs of k-step ks (two register sets)
+      i32x2 ax[2][TR], bx[2][TC];
+      f32x4 ga[2], gb[2];
+      auto issue = [&](int ks, int b) {
+#pragma unroll
+        for (int i = 0; i < TR; ++i) lds_tr8(ax[b][i], sbase + offA, 2 * i * CS + ks * 256);
+#pragma unroll
+        for (int j = 0; j < TC; ++j) lds_tr8(bx[b][j], sbase + offB, 2 * j * CS + ks * 256);
+        lds_rd128f(ga[b], gbase, ks * 64);
+        lds_rd128f(gb[b], gbase, ks * 64 + 16);
+      };
+      issue(0, 0);
+#pragma unroll
+      for (int ks = 0; ks < KB / 16; ++ks) {
+        const int b = ks & 1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // element j of a fragment is stage row 16 ks + 8 hh + j: eight (g Ls), packed to f16 pairs (same for the half-wave)
+        const u32x4 gpk = {pack2h(ga[b][0] * ls, ga[b][1] * ls), pack2h(ga[b][2] * ls, ga[b][3] * ls),
+                           pack2h(gb[b][0] * ls, gb[b][1] * ls), pack2h(gb[b][2] * ls, gb[b][3] * ls)};
+        const f16x8_t gp = __builtin_bit_cast(f16x8_t, gpk);
+        u32x4 af[TR], bf[TC];
+#pragma unroll
+        for (int i = 0; i < TR; ++i) {
+          af[i] = bf8x8_to_f16(ax[b][i]);
+          if (lastl) af[i] = __builtin_bit_cast(u32x4, __builtin_bit_cast(f16x8_t, af[i]) * afix[i]);
+        }
+#pragma unroll
+        for (int j = 0; j < TC; ++j) bf[j] = __builtin_bit_cast(u32x4, __builtin_bit_cast(f16x8_t, bf8x8_to_f16(bx[b][j])) * gp);
+        if (ks + 1 < KB / 16) issue(ks + 1, b ^ 1);
+#pragma unroll
+        for (int i = 0; i < TR; ++i) {
+#pragma unroll
+          for (int j = 0; j < TC; ++j) acc[i][j] = mfma_f16(af[i], bf[j], acc[i][j]);
+          if (i == wc) accb = mfma_f16(af[i], gpk, accb);          // (wc < TR: wave-uniform)
+        }
+      }
+    }
+  }
+  float* P = a.partial + ((size_t)layer * a.n_splits + split) * F * F;
+  if (active) {
+#pragma unroll
+    for (int i = 0; i < TR; ++i)
+#pragma unroll
+      for (int j = 0; j < TC; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          P[(size_t)fperm8(32 * (wr * TR + i) + rowperm(r) + 4 * hh) * F + fperm8(32 * (wc * TC + j) + col)] = acc[i][j][r];
+  }
+  if (has_bias && col == 0) {        // every column of accb holds the row sums
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      a.partial2[((size_t)layer * a.n_splits + split) * (F + 4) + fperm8(32 * (wr * TR + wc) + rowperm(r) + 4 * hh)] = accb[r];
   }
 }
 
@@ -944,7 +1173,7 @@ __global__ void __launch_bounds__(F) k_small_from_groups(const WgradArgs a) {
   int64_t g0 = (int64_t)blockIdx.x * per, g1 = g0 + per;
   if (g1 > ngroups) g1 = ngroups;
   constexpr int RS = 3 * F + 8;
-  const float* base = (const float*)((const char*)a.stash_h + (size_t)a.n_hidden * a.stride_rows * F * 2);
+  const float* base = (const float*)((const char*)a.stash_h + (size_t)a.n_hidden * a.stride_rows * F * a.stash_esz);
   float aw = 0.f, a0 = 0.f, ax = 0.f, ay = 0.f, az = 0.f, sg = 0.f;
 #pragma unroll 4
   for (int64_t g = g0; g < g1; ++g) {

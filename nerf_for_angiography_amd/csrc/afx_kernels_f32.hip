@@ -530,7 +530,7 @@ __global__ void k_reduce_w(const ReduceArgs a) {
   for (int sp = 0; sp < a.n_splits; ++sp) s += a.partial[((size_t)layer * a.n_splits + sp) * F * F + e];
   // flat layout: W0[F,k0] b0[F] then (W_l[F,F] b_l[F])*, Wout[F] bout
   size_t off = layer == 0 ? 0 : (size_t)F * a.k0 + F + (size_t)(layer - 1) * (F * F + F);
-  if (a.gmax) s *= ldexpf(1.f, wgrad_scale_exp(a.gmax));       // f16 mode (hidden layers only reach here): undo Ls, exact
+  if (a.gmax) s *= ldexpf(1.f, wgrad_scale_exp(a.gmax) - a.scale_shift);       // f16 mode (hidden layers only reach here): undo Ls, exact
   a.grad[off + (size_t)row * ncr + c] += s;
 }
 
@@ -546,7 +546,7 @@ __global__ void k_reduce_b(const ReduceArgs a) {
     if (y == a.n_hidden + 1 && f == 0) sg += P[F];
   }
   const size_t hidden0 = (size_t)F * a.k0 + F;
-  if (a.gmax) s *= ldexpf(1.f, wgrad_scale_exp(a.gmax));
+  if (a.gmax) s *= ldexpf(1.f, wgrad_scale_exp(a.gmax) - a.scale_shift);
   if (y == 0) a.grad[(size_t)F * a.k0 + f] += s;
   else if (y <= a.n_hidden) a.grad[hidden0 + (size_t)(y - 1) * (F * F + F) + (size_t)F * F + f] += s;
   else {

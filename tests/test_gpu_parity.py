@@ -83,8 +83,9 @@ def test_mlp_forward_fourier_golden(golden):
 TOL = {"f32": dict(mlp=1e-5, pix=1e-5, grad=1e-4),
        "bf16x3": dict(mlp=5e-5, pix=1e-4, grad=3e-2),
        "f16": dict(mlp=1.5e-3, pix=1e-4, grad=1e-2),
+       "f16s8": dict(mlp=1.5e-3, pix=1e-4, grad=2e-2),     # f16 arithmetic, bf8 backward stash: same pixels, measured gradients 6e-3
        "bf16": dict(mlp=3e-2, pix=1e-2, grad=6e-2)}
-PIX_C1 = {"bf16x3": 1e-4, "f16": 2e-4, "bf16": 1e-2}      # the 4x64 / 32-sample C1 fixture (see above)
+PIX_C1 = {"bf16x3": 1e-4, "f16": 2e-4, "f16s8": 2e-4, "bf16": 1e-2}      # the 4x64 / 32-sample C1 fixture (see above)
 
 
 @pytest.mark.parametrize("prec", ["bf16x3", "f16", "bf16"])
@@ -109,7 +110,7 @@ def test_mlp_forward_barf_golden_bf16(golden, prec):
         assert rel_l2(y.cpu().numpy(), g[f"y_alpha{a}"]) < 2 * TOL[prec]["mlp"], a
 
 
-@pytest.mark.parametrize("prec", ["bf16x3", "f16", "bf16"])
+@pytest.mark.parametrize("prec", ["bf16x3", "f16", "f16s8", "bf16"])
 def test_fused_render_acc_golden_bf16(golden, prec):
     from nerf_for_angiography_amd.render import render_rays
     g, m, near, far, s = _c1(golden, prec)
@@ -124,7 +125,7 @@ def test_fused_render_acc_golden_bf16(golden, prec):
         assert rel_l2(got[k], g["acc_grad__" + k]) < TOL[prec]["grad"], k
 
 
-@pytest.mark.parametrize("prec", ["bf16x3", "f16", "bf16"])
+@pytest.mark.parametrize("prec", ["bf16x3", "f16", "f16s8", "bf16"])
 def test_c2_scale_vs_oracle_bf16(prec):
     """8x256 MLP, 64 / 50 samples per ray, ragged ray count, vs the CPU oracle; plus bit-identical re-runs."""
     from oracle import angio_oracle as orc
@@ -162,7 +163,7 @@ def test_c2_scale_vs_oracle_bf16(prec):
             assert np.array_equal(v, g1[k]), k
 
 
-@pytest.mark.parametrize("prec", ["bf16x3", "f16", "bf16"])
+@pytest.mark.parametrize("prec", ["bf16x3", "f16", "f16s8", "bf16"])
 def test_fused_train_step_matches_autograd_path(golden, prec):
     """afx_train_step_mse (in-kernel compositing + MSE gradient) == render -> mse_loss -> backward with the same
     bf16 backward kernel; and both sit within the bf16 gradient tolerance of the reference fixture."""
@@ -177,12 +178,12 @@ def test_fused_train_step_matches_autograd_path(golden, prec):
     spec = RenderSpec(n_rays=o.shape[0], n_samples=s, origins=o, dirs=d, mode="acc", t_near=near, t_far=far)
     loss_f, pix = train_step_mse(m, spec, tgt)
     gf = _grads_by_name(m)
-    btol = "f16" if prec == "f16" else "bf16"       # bf16x3: the fused step's forward is the plain-bf16 backward kernel's
+    btol = prec if prec in ("f16", "f16s8") else "bf16"       # bf16x3: the fused step's forward is the plain-bf16 backward kernel's
     assert rel_l2(pix.cpu().numpy(), g["acc_rgb"]) < PIX_C1[btol]
-    np.testing.assert_allclose(float(loss_f), float(g["acc_loss"]), rtol=2e-2 if prec != "f16" else 5e-4)
+    np.testing.assert_allclose(float(loss_f), float(g["acc_loss"]), rtol=2e-2 if prec not in ("f16", "f16s8") else 5e-4)
     for k in gf:
         assert rel_l2(gf[k], g["acc_grad__" + k]) < TOL[btol]["grad"], k
-        if prec in ("bf16", "f16"):      # same kernels, same pixels -> same gradients up to the fp32 loss-gradient rounding
+        if prec in ("bf16", "f16", "f16s8"):      # same kernels, same pixels -> same gradients up to the fp32 loss-gradient rounding
             assert rel_l2(gf[k], ga[k]) < 1e-5, k
     # gradient accumulation semantics of loss.backward()
     train_step_mse(m, spec, tgt)
@@ -557,6 +558,14 @@ def test_full_size_projection_properties():
     assert float((pix1 - a).abs().max()) < 1e-6          # the step's forward IS the rendering arithmetic
     for k, v in g32.items():
         assert rel_l2(g1[k], v) < TOL["f16"]["grad"], k
+    m.precision = "f16s8"                                # bf8 stash: same pixels, gradients within its own tolerance
+    m.zero_grad()
+    loss8, pix8 = train_step_mse(m, spec, tgt)
+    g8 = _grads_by_name(m)
+    assert torch.equal(pix8, pix1)
+    for k, v in g32.items():
+        assert rel_l2(g8[k], v) < TOL["f16s8"]["grad"], k
+    m.precision = "f16"
     m.engine.max_workspace_bytes = 9 << 30
     m.engine._ws = None
     m.zero_grad()
@@ -567,7 +576,7 @@ def test_full_size_projection_properties():
         assert rel_l2(g2[k], g1[k]) < 1e-5, k
 
 
-@pytest.mark.parametrize("prec", ["f16", "bf16"])
+@pytest.mark.parametrize("prec", ["f16", "f16s8", "bf16"])
 def test_production_build_is_bit_identical_to_the_safe_waits_build(prec):
     """Race detector for the hand-counted s_waitcnt vmcnt / lgkmcnt protocol of the chain kernels: libafx_safe.so is the
     same source with every counted wait replaced by a full one (-DAFX_SAFE_WAITS).  A deterministic under-wait would
