@@ -123,7 +123,10 @@ enum { AFX_DEPTH_UNIFORM_MID = 0, /* t_s = near+i*step, t_e = t_s+step, evaluate
                                      acc_ray_marching w/o grid + acc_render_volume_density, nerf_helpers_acc.py:10-63 */
        AFX_DEPTH_SHARED_Z = 1,    /* z[S] shared by all rays; render_volume_density, nerf_helpers.py:59-123:
                                      dt_i = (z[i+1]-z[i])*||d||, last dt = 1e10*||d||                                   */
-       AFX_DEPTH_PER_RAY_Z = 2 }; /* z[R,S] (hierarchical sampling, nerf_helpers.py:178-195); same convention   */
+       AFX_DEPTH_PER_RAY_Z = 2,   /* z[R,S] (hierarchical sampling, nerf_helpers.py:178-195); same convention   */
+       AFX_DEPTH_STRATIFIED = 3 };/* randomize_depth (nerf_helpers.py:13-22) of z = linspace(t_near, t_far, S) IN the kernel:
+                                     one jitter vector per call from Philox stream (jitter_seed, jitter_stream);
+                                     render_volume_density convention.  Perf mode: parity mode passes the host's z (SHARED_Z) */
 
 typedef struct afx_render_args {
   int64_t n_rays;
@@ -144,6 +147,7 @@ typedef struct afx_render_args {
   float* tau;                  /* optional out [R,S]: sigma*dt (optical depth per sample) */
   void* workspace;
   size_t workspace_bytes;
+  uint64_t jitter_seed, jitter_stream;   /* AFX_DEPTH_STRATIFIED */
 } afx_render_args;
 
 /* Fused ray generation -> sampling -> encoding -> MLP -> Beer-Lambert product.
@@ -205,6 +209,66 @@ int afx_fine_depths(const float* z_coarse, int z_per_ray, const float* w_coarse,
  * type_ct != 0: img = prod exp(-mu*dz*||d||), last dz = 1e10;  type_ct == 0: img = prod exp(-mu). */
 int afx_project_volume(const float* vol, int32_t nx, int32_t ny, int32_t nz, const double origin[3], const double spacing[3],
                        float fill_value, const afx_render_args* args, int type_ct, void* stream);
+
+/* ---- Occupancy-grid acceleration of the training loop (nerf/run_nerf_acc.py:196-198,284-287;
+ * nerf/nerf_helpers_acc.py:10-31,65-78).  Upstream these are nerfacc 0.3.x calls (OccupancyGrid.every_n_step,
+ * ray_marching with alpha_fn, render_visibility); nerfacc is neither vendored nor pinned by the reference and absent
+ * here, so the entry points implement its published algorithm (parity unpinned at that boundary; restated for the
+ * tests in oracle/).  The MLP evaluations between the steps are afx_mlp_infer calls on the points emitted here;
+ * exclusive scans of the per-ray counts are the caller's (one cumsum).  All buffers are the caller's. */
+typedef struct afx_grid_desc {
+  float roi_aabb[6];            /* xmin ymin zmin xmax ymax zmax */
+  int32_t resolution[3];
+} afx_grid_desc;
+
+/* OccupancyGrid._update, step 1: x = (cell + u) / resolution * (hi - lo) + lo for the n selected cells (cell_idx NULL:
+ * cells 0..n-1).  jitter[n,3] in [0,1) supplied by the caller (parity mode), or NULL: drawn in-kernel from the
+ * counter-based Philox4x32-10 stream (seed, stream_id) (perf mode). */
+int afx_grid_points(const afx_grid_desc* grid, const int32_t* cell_idx, int64_t n, const float* jitter, uint64_t seed,
+                    uint64_t stream_id, float* pts, void* stream);
+/* step 2: occs[c] = max(occs[c] * ema_decay, occ_new) for the selected cells; deterministic when a cell is selected more
+ * than once (max over its draws).  occs_scratch: n_cells floats (snapshot of occs). */
+int afx_grid_update(const afx_grid_desc* grid, float* occs, float* occs_scratch, const int32_t* cell_idx, int64_t n,
+                    const float* occ_new, float ema_decay, void* stream);
+/* step 3: binary[c] = occs[c] > min(mean(occs), occ_thre) as bytes (the module's `binary` tensor) and as the packed
+ * bitfield the march reads (n_cells/32 words, rounded up).  partial_ws: 256 doubles. */
+int afx_grid_binarize(const afx_grid_desc* grid, const float* occs, float occ_thre, uint8_t* binary, uint32_t* bits,
+                      double* partial_ws, void* stream);
+
+/* nerfacc.ray_marching: t range = ray / scene_aabb intersection clipped to [near, far]; fixed-step lattice
+ * t_min + k*step; a step is kept when the cell holding its mid-point is occupied (grid_bits NULL: every step). */
+typedef struct afx_march_args {
+  const float* origins;         /* [R,3] */
+  const float* dirs;            /* [R,3] */
+  int64_t n_rays;
+  int32_t has_aabb;  float scene_aabb[6];
+  int32_t has_near, has_far;  float near_plane, far_plane;
+  float step;                   /* render_step_size */
+  const uint32_t* grid_bits;    /* from afx_grid_binarize, or NULL */
+  afx_grid_desc grid;
+} afx_march_args;
+int afx_march_count(const afx_march_args* args, int32_t* counts, void* stream);                    /* kept steps per ray */
+/* packed, ray-sorted samples at offsets = exclusive scan of the counts; mid_points optional [n,3] = o + d*(t_s+t_e)/2 */
+int afx_march_write(const afx_march_args* args, const int64_t* offsets, int32_t* ray_indices, float* t_starts,
+                    float* t_ends, float* mid_points, void* stream);
+/* alpha_fn of nerf_helpers_acc.py:11-25 on the raw MLP output of the candidates + nerfacc's render_visibility: steps with
+ * alpha < alpha_thre are dropped without attenuating the transmittance, the ray ends once it falls below early_stop_eps.
+ * input_is_alpha != 0: `raw` already holds the caller's alpha_fn values.  offsets[R+1]; keep[n] in {0,1}; counts[r] = kept steps. */
+int afx_march_visibility(const float* raw, int32_t input_is_alpha, const float* t_starts, const float* t_ends, const int64_t* offsets,
+                         int64_t n_rays, float early_stop_eps, float alpha_thre, uint8_t* keep, int32_t* counts, void* stream);
+int afx_march_compact(const uint8_t* keep, const int64_t* offsets_in, const int64_t* offsets_out, int64_t n_rays,
+                      const float* t_starts_in, const float* t_ends_in, int32_t* ray_indices_out, float* t_starts_out,
+                      float* t_ends_out, void* stream);
+
+/* ---- Device-resident ray batches (sample_pixel_rays, nerf/nerf_helpers.py:137-150: weighted sampling without
+ * replacement over all pixels of all training projections).  keys[i] = log(u_i) / w_i (Efraimidis-Spirakis): the k
+ * largest keys are a weighted sample without replacement; u[n] supplied, or NULL: Philox stream (seed, stream_id).
+ * afx_gather_rays copies the selected rows of the resident ray table. */
+int afx_sample_keys(const float* weights, int64_t n, const float* u, uint64_t seed, uint64_t stream_id, float* keys, void* stream);
+int afx_gather_rays(const float* origins, const float* dirs, const float* pixels, const int64_t* idx, int64_t k,
+                    float* origins_out, float* dirs_out, float* pixels_out, void* stream);
+/* out[i] = uniform [0,1) number i of Philox4x32-10 stream (seed, stream_id): the generator of every "perf mode" draw */
+int afx_philox_uniform(uint64_t seed, uint64_t stream_id, int64_t n, float* out, void* stream);
 
 /* Measurement aid (bench.py's roofline leg): when enabled, every launch of the three MFMA kernels is
  * bracketed by HIP events recorded on the launch stream.  afx_profile_read blocks on those events

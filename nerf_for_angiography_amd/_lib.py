@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libafx.so")
 ENC = {"none": 0, "barf": 1, "fourier": 2}
 PREC = {"f32": 0, "bf16x3": 1, "bf16": 2, "f16": 3, "f16s8": 4}
 RAYS_ARRAYS, RAYS_POSE = 0, 1
-DEPTH_UNIFORM_MID, DEPTH_SHARED_Z, DEPTH_PER_RAY_Z = 0, 1, 2
+DEPTH_UNIFORM_MID, DEPTH_SHARED_Z, DEPTH_PER_RAY_Z, DEPTH_STRATIFIED = 0, 1, 2, 3
 Q_PARAM_COUNT, Q_K0, Q_PREPARED_BYTES, Q_FWD_WORKSPACE, Q_BWD_WORKSPACE_MIN, Q_BWD_WORKSPACE_FULL = range(6)
 
 
@@ -28,7 +28,17 @@ class RenderArgs(C.Structure):
                 ("ray_id0", C.c_int64), ("width", C.c_int32), ("height", C.c_int32), ("focal", C.c_double),
                 ("depth_mode", C.c_int32), ("t_near", C.c_float), ("t_far", C.c_float), ("z", C.c_void_p),
                 ("pixel", C.c_void_p), ("sigma", C.c_void_p), ("tau", C.c_void_p), ("workspace", C.c_void_p),
-                ("workspace_bytes", C.c_size_t)]
+                ("workspace_bytes", C.c_size_t), ("jitter_seed", C.c_uint64), ("jitter_stream", C.c_uint64)]
+
+
+class GridDesc(C.Structure):
+    _fields_ = [("roi_aabb", C.c_float * 6), ("resolution", C.c_int32 * 3)]
+
+
+class MarchArgs(C.Structure):
+    _fields_ = [("origins", C.c_void_p), ("dirs", C.c_void_p), ("n_rays", C.c_int64), ("has_aabb", C.c_int32),
+                ("scene_aabb", C.c_float * 6), ("has_near", C.c_int32), ("has_far", C.c_int32), ("near_plane", C.c_float),
+                ("far_plane", C.c_float), ("step", C.c_float), ("grid_bits", C.c_void_p), ("grid", GridDesc)]
 
 
 _SIGS = {
@@ -61,6 +71,19 @@ _SIGS = {
     "afx_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "afx_fine_depths": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                   C.c_void_p, C.c_void_p]),
+    "afx_grid_points": (C.c_int, [C.POINTER(GridDesc), C.c_void_p, C.c_int64, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "afx_grid_update": (C.c_int, [C.POINTER(GridDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_float, C.c_void_p]),
+    "afx_grid_binarize": (C.c_int, [C.POINTER(GridDesc), C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "afx_march_count": (C.c_int, [C.POINTER(MarchArgs), C.c_void_p, C.c_void_p]),
+    "afx_march_write": (C.c_int, [C.POINTER(MarchArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "afx_march_visibility": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]),
+    "afx_march_compact": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]),
+    "afx_sample_keys": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "afx_gather_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p]),
+    "afx_philox_uniform": (C.c_int, [C.c_uint64, C.c_uint64, C.c_int64, C.c_void_p, C.c_void_p]),
 }
 
 _libs = {}

@@ -10,6 +10,7 @@
 #include "afx_internal.h"
 #include "afx_kernels_f32.hip"
 #include "afx_kernels_bf16.hip"
+#include "afx_kernels_grid.hip"
 #include "afx_inst.h"
 #include <set>
 
@@ -410,6 +411,8 @@ static int check_render(const afx_ctx* c, const afx_render_args* r, const char* 
     if (!(r->t_far > r->t_near)) return fail(AFX_E_INVALID, "%s: need t_far > t_near", who);
   } else if (r->depth_mode == AFX_DEPTH_SHARED_Z || r->depth_mode == AFX_DEPTH_PER_RAY_Z) {
     if (!r->z) return fail(AFX_E_INVALID, "%s: z required for this depth_mode", who);
+  } else if (r->depth_mode == AFX_DEPTH_STRATIFIED) {
+    if (!(r->t_far > r->t_near)) return fail(AFX_E_INVALID, "%s: need t_far > t_near", who);
   } else return fail(AFX_E_INVALID, "%s: bad depth_mode %d", who, r->depth_mode);
   if (!r->pixel) return fail(AFX_E_INVALID, "%s: pixel required", who);
   if (r->n_rays * s_pad_of(r->n_samples) > ((int64_t)1 << 31) - 256)
@@ -423,7 +426,8 @@ static void fill_render(const afx_render_args* r, ChainArgs& a) {
   a.poses = r->ray_mode == AFX_RAYS_POSE ? r->poses : nullptr;
   a.ray_ids = r->ray_ids; a.ray_id0 = r->ray_id0; a.width = r->width; a.height = r->height; a.focal = r->focal;
   a.n_samples = r->n_samples; a.s_pad = (int)s_pad_of(r->n_samples); a.depth_mode = r->depth_mode;
-  a.t_near = r->t_near;
+  a.t_near = r->t_near; a.t_far = r->t_far;
+  a.jitter_seed = r->jitter_seed; a.jitter_stream = r->jitter_stream;
   a.t_step = (float)((double)(r->t_far - r->t_near) / r->n_samples);
   a.z = r->z;
   a.n_total = r->n_rays * a.s_pad;
@@ -745,6 +749,150 @@ extern "C" int afx_fine_depths(const float* z_coarse, int z_per_ray, const float
   if (n_rays <= 0) return AFX_OK;
   hipLaunchKernelGGL(k_fine_depths, dim3((unsigned)((n_rays + 63) / 64)), dim3(64), 0, (hipStream_t)stream, z_coarse, z_per_ray,
                      w_coarse, u, n_rays, n_coarse, n_fine, z_out);
+  HIPCHK(hipGetLastError());
+  return AFX_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------- occupancy grid, march, sampler
+static GridDesc grid_of(const afx_grid_desc* g) {
+  GridDesc d;
+  for (int i = 0; i < 3; ++i) { d.lo[i] = g->roi_aabb[i]; d.hi[i] = g->roi_aabb[3 + i]; d.res[i] = g->resolution[i]; }
+  return d;
+}
+static int check_grid(const afx_grid_desc* g, const char* who, int64_t* n_cells) {
+  if (!g) return fail(AFX_E_INVALID, "%s: null grid", who);
+  for (int i = 0; i < 3; ++i) {
+    if (g->resolution[i] < 1 || g->resolution[i] > 2048) return fail(AFX_E_INVALID, "%s: resolution must be in 1..2048", who);
+    if (!(g->roi_aabb[3 + i] > g->roi_aabb[i])) return fail(AFX_E_INVALID, "%s: empty roi_aabb", who);
+  }
+  *n_cells = (int64_t)g->resolution[0] * g->resolution[1] * g->resolution[2];
+  return AFX_OK;
+}
+static inline dim3 blocks_for(int64_t n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
+
+extern "C" int afx_grid_points(const afx_grid_desc* grid, const int32_t* cell_idx, int64_t n, const float* jitter, uint64_t seed,
+                               uint64_t stream_id, float* pts, void* stream) {
+  int64_t nc;
+  if (int rc = check_grid(grid, "afx_grid_points", &nc)) return rc;
+  if (n < 0 || (!cell_idx && n > nc)) return fail(AFX_E_INVALID, "afx_grid_points: n out of range");
+  if (n == 0) return AFX_OK;
+  if (!pts) return fail(AFX_E_INVALID, "afx_grid_points: null pts");
+  hipLaunchKernelGGL(k_grid_points, blocks_for(n), dim3(256), 0, (hipStream_t)stream, cell_idx, n, jitter, seed, stream_id, grid_of(grid), pts);
+  HIPCHK(hipGetLastError());
+  return AFX_OK;
+}
+
+extern "C" int afx_grid_update(const afx_grid_desc* grid, float* occs, float* occs_scratch, const int32_t* cell_idx, int64_t n,
+                               const float* occ_new, float ema_decay, void* stream) {
+  int64_t nc;
+  if (int rc = check_grid(grid, "afx_grid_update", &nc)) return rc;
+  if (n < 0 || (!cell_idx && n > nc)) return fail(AFX_E_INVALID, "afx_grid_update: n out of range");
+  if (n == 0) return AFX_OK;
+  if (!occs || !occs_scratch || !occ_new) return fail(AFX_E_INVALID, "afx_grid_update: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(hipMemcpyAsync(occs_scratch, occs, (size_t)nc * 4, hipMemcpyDeviceToDevice, st));
+  hipLaunchKernelGGL(k_grid_decay, blocks_for(n), dim3(256), 0, st, occs, (const float*)occs_scratch, cell_idx, n, ema_decay);
+  hipLaunchKernelGGL(k_grid_ema, blocks_for(n), dim3(256), 0, st, occs, cell_idx, occ_new, n);
+  HIPCHK(hipGetLastError());
+  return AFX_OK;
+}
+
+extern "C" int afx_grid_binarize(const afx_grid_desc* grid, const float* occs, float occ_thre, uint8_t* binary, uint32_t* bits,
+                                 double* partial_ws, void* stream) {
+  int64_t nc;
+  if (int rc = check_grid(grid, "afx_grid_binarize", &nc)) return rc;
+  if (!occs || !binary || !bits || !partial_ws) return fail(AFX_E_INVALID, "afx_grid_binarize: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  const int np = 256;
+  hipLaunchKernelGGL(k_grid_sum, dim3(np), dim3(256), 0, st, occs, nc, partial_ws);
+  hipLaunchKernelGGL(k_grid_binarize, blocks_for((nc + 31) / 32), dim3(256), 0, st, occs, nc, (const double*)partial_ws, np, occ_thre, binary, bits);
+  HIPCHK(hipGetLastError());
+  return AFX_OK;
+}
+
+static int fill_march(const afx_march_args* m, MarchArgs& a, const char* who) {
+  if (!m) return fail(AFX_E_INVALID, "%s: null args", who);
+  if (m->n_rays < 0) return fail(AFX_E_INVALID, "%s: n_rays < 0", who);
+  if (m->n_rays > 0 && (!m->origins || !m->dirs)) return fail(AFX_E_INVALID, "%s: origins/dirs required", who);
+  if (!(m->step > 0.f)) return fail(AFX_E_INVALID, "%s: step must be > 0", who);
+  a.org = m->origins; a.dir = m->dirs; a.n_rays = m->n_rays;
+  a.has_aabb = m->has_aabb;
+  for (int i = 0; i < 6; ++i) a.aabb[i] = m->scene_aabb[i];
+  a.has_near = m->has_near; a.has_far = m->has_far; a.near_plane = m->near_plane; a.far_plane = m->far_plane;
+  a.dt = m->step; a.bits = m->grid_bits;
+  if (m->grid_bits) {
+    int64_t nc;
+    if (int rc = check_grid(&m->grid, who, &nc)) return rc;
+    a.g = grid_of(&m->grid);
+  } else a.g = GridDesc{};
+  if (!m->has_aabb && !m->has_far) return fail(AFX_E_INVALID, "%s: an unbounded ray needs scene_aabb or far_plane", who);
+  return AFX_OK;
+}
+
+extern "C" int afx_march_count(const afx_march_args* args, int32_t* counts, void* stream) {
+  MarchArgs a;
+  if (int rc = fill_march(args, a, "afx_march_count")) return rc;
+  if (a.n_rays == 0) return AFX_OK;
+  if (!counts) return fail(AFX_E_INVALID, "afx_march_count: null counts");
+  hipLaunchKernelGGL(k_march_count, blocks_for(a.n_rays, 64), dim3(64), 0, (hipStream_t)stream, a, counts);
+  HIPCHK(hipGetLastError());
+  return AFX_OK;
+}
+
+extern "C" int afx_march_write(const afx_march_args* args, const int64_t* offsets, int32_t* ray_indices, float* t_starts,
+                               float* t_ends, float* mid_points, void* stream) {
+  MarchArgs a;
+  if (int rc = fill_march(args, a, "afx_march_write")) return rc;
+  if (a.n_rays == 0) return AFX_OK;
+  if (!offsets || !ray_indices || !t_starts || !t_ends) return fail(AFX_E_INVALID, "afx_march_write: null argument");
+  hipLaunchKernelGGL(k_march_write, blocks_for(a.n_rays, 64), dim3(64), 0, (hipStream_t)stream, a, offsets, ray_indices, t_starts, t_ends, mid_points);
+  HIPCHK(hipGetLastError());
+  return AFX_OK;
+}
+
+extern "C" int afx_march_visibility(const float* raw, int32_t input_is_alpha, const float* t_starts, const float* t_ends, const int64_t* offsets,
+                                    int64_t n_rays, float early_stop_eps, float alpha_thre, uint8_t* keep, int32_t* counts, void* stream) {
+  if (n_rays <= 0) return AFX_OK;
+  if (!offsets || !keep || !counts) return fail(AFX_E_INVALID, "afx_march_visibility: null argument");
+  hipLaunchKernelGGL(k_march_visibility, blocks_for(n_rays, 64), dim3(64), 0, (hipStream_t)stream, raw, (int)input_is_alpha, t_starts, t_ends, offsets, n_rays,
+                     early_stop_eps, alpha_thre, keep, counts);
+  HIPCHK(hipGetLastError());
+  return AFX_OK;
+}
+
+extern "C" int afx_march_compact(const uint8_t* keep, const int64_t* offsets_in, const int64_t* offsets_out, int64_t n_rays,
+                                 const float* t_starts_in, const float* t_ends_in, int32_t* ray_indices_out, float* t_starts_out,
+                                 float* t_ends_out, void* stream) {
+  if (n_rays <= 0) return AFX_OK;
+  if (!keep || !offsets_in || !offsets_out) return fail(AFX_E_INVALID, "afx_march_compact: null argument");
+  hipLaunchKernelGGL(k_march_compact, blocks_for(n_rays, 64), dim3(64), 0, (hipStream_t)stream, keep, offsets_in, offsets_out, n_rays,
+                     t_starts_in, t_ends_in, ray_indices_out, t_starts_out, t_ends_out);
+  HIPCHK(hipGetLastError());
+  return AFX_OK;
+}
+
+extern "C" int afx_sample_keys(const float* weights, int64_t n, const float* u, uint64_t seed, uint64_t stream_id, float* keys, void* stream) {
+  if (n <= 0) return AFX_OK;
+  if (!keys) return fail(AFX_E_INVALID, "afx_sample_keys: null keys");
+  hipLaunchKernelGGL(k_sample_keys, blocks_for(n), dim3(256), 0, (hipStream_t)stream, weights, n, u, seed, stream_id, keys);
+  HIPCHK(hipGetLastError());
+  return AFX_OK;
+}
+
+extern "C" int afx_gather_rays(const float* origins, const float* dirs, const float* pixels, const int64_t* idx, int64_t k,
+                               float* origins_out, float* dirs_out, float* pixels_out, void* stream) {
+  if (k <= 0) return AFX_OK;
+  if (!origins || !dirs || !idx || !origins_out || !dirs_out) return fail(AFX_E_INVALID, "afx_gather_rays: null argument");
+  hipLaunchKernelGGL(k_gather_rays, blocks_for(k), dim3(256), 0, (hipStream_t)stream, origins, dirs, pixels, idx, k, origins_out, dirs_out, pixels_out);
+  HIPCHK(hipGetLastError());
+  return AFX_OK;
+}
+
+extern "C" int afx_philox_uniform(uint64_t seed, uint64_t stream_id, int64_t n, float* out, void* stream) {
+  if (n <= 0) return AFX_OK;
+  if (!out) return fail(AFX_E_INVALID, "afx_philox_uniform: null out");
+  hipLaunchKernelGGL(k_philox_fill, blocks_for(n), dim3(256), 0, (hipStream_t)stream, seed, stream_id, n, out);
   HIPCHK(hipGetLastError());
   return AFX_OK;
 }

@@ -49,6 +49,8 @@ struct ChainArgs {
   double focal;
   int32_t n_samples, s_pad, depth_mode;
   float t_near, t_step;
+  float t_far;              // AFX_DEPTH_STRATIFIED
+  uint64_t jitter_seed, jitter_stream;
   const float* z;
   // outputs
   float* out;               // points mode

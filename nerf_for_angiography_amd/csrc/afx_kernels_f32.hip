@@ -101,6 +101,36 @@ __device__ __forceinline__ void load_ray(const ChainArgs& a, int r, float& ox, f
   dx = (float)dv[0]; dy = (float)dv[1]; dz = (float)dv[2];
 }
 
+// Counter-based uniform number (Philox4x32-10; the same function as afx_kernels_grid.hip's philox_uniform - kept here
+// because this file is also compiled into the chain-kernel translation units)
+__device__ __forceinline__ float chain_philox(uint64_t seed, uint64_t stream, uint64_t i) {
+  uint32_t c0 = (uint32_t)(i >> 2), c1 = (uint32_t)(i >> 34), c2 = (uint32_t)stream, c3 = (uint32_t)(stream >> 32);
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  const uint32_t o[4] = {c0, c1, c2, c3};
+  return (float)(o[i & 3] >> 8) * (1.0f / 16777216.0f);
+}
+// stratified depth i of AFX_DEPTH_STRATIFIED: z = near (1 - t) + far t, t = i / (S - 1); mids = .5 (z[1:] + z[:-1]);
+// lower = [z0, mids], upper = [mids, z_last]; z' = lower + (upper - lower) u
+__device__ __forceinline__ float strat_z(const ChainArgs& a, int i) {
+  const int S = a.n_samples;
+  auto zl = [&](int k) {
+    const float t = __fdiv_rn((float)k, (float)(S - 1));
+    return __fadd_rn(__fmul_rn(a.t_near, __fsub_rn(1.f, t)), __fmul_rn(a.t_far, t));
+  };
+  const float zi = zl(i);
+  const float lower = i > 0 ? 0.5f * __fadd_rn(zi, zl(i - 1)) : zi;
+  const float upper = i + 1 < S ? 0.5f * __fadd_rn(zl(i + 1), zi) : zi;
+  const float u = chain_philox(a.jitter_seed, a.jitter_stream, (uint64_t)i);
+  return __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), u));
+}
+
 __device__ __forceinline__ Sample make_sample(const ChainArgs& a, int64_t n) {
   Sample sp;
   sp.px = sp.py = sp.pz = 0.f; sp.dt = 0.f; sp.ray = 0; sp.s = 0; sp.live = false;
@@ -127,6 +157,16 @@ __device__ __forceinline__ Sample make_sample(const ChainArgs& a, int64_t n) {
     sp.py = __fadd_rn(oy, __fmul_rn(dy, q) * 0.5f);
     sp.pz = __fadd_rn(oz, __fmul_rn(dz, q) * 0.5f);
     sp.dt = sp.live ? __fsub_rn(te, ts) : 0.f;
+  } else if (a.depth_mode == 3) {
+    // randomize_depth (nerf/nerf_helpers.py:13-22) of z = linspace(near, far, S) in the kernel: one jitter vector per
+    // call, u_i = Philox(jitter_seed, jitter_stream)[i]; then the render_volume_density convention
+    const float zs = strat_z(a, s);
+    sp.px = __fadd_rn(ox, __fmul_rn(dx, zs));
+    sp.py = __fadd_rn(oy, __fmul_rn(dy, zs));
+    sp.pz = __fadd_rn(oz, __fmul_rn(dz, zs));
+    const float dist = s + 1 < a.n_samples ? __fsub_rn(strat_z(a, s + 1), zs) : 1e10f;
+    const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+    sp.dt = sp.live ? __fmul_rn(dist, nrm) : 0.f;
   } else {
     const float* zr = a.depth_mode == 2 ? a.z + (int64_t)r * a.n_samples : a.z;
     const float zs = zr[s];
@@ -148,6 +188,8 @@ __device__ __forceinline__ void ray_param(const ChainArgs& a, const Sample& sp, 
   if (a.depth_mode == 0) {
     const float ts = __fadd_rn(a.t_near, __fmul_rn((float)sp.s, a.t_step));
     t = __fadd_rn(ts, __fadd_rn(ts, a.t_step)) * 0.5f;
+  } else if (a.depth_mode == 3) {
+    t = strat_z(a, sp.s);
   } else {
     const float* zr = a.depth_mode == 2 ? a.z + (int64_t)sp.ray * a.n_samples : a.z;
     t = zr[sp.s];

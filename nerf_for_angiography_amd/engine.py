@@ -34,7 +34,8 @@ class RenderSpec:
     Rays: either origins/dirs [R,3] fp32 (what sample_pixel_rays returns), or poses [n_proj,3,4] float64 +
     ray_ids (int32 index into [n_proj,H,W]; None => rays ray_id0 .. ray_id0+R-1) + width/height/focal
     (in-kernel get_ray_values).  Depths: mode 'acc' (uniform mid-point march t_near..t_far, the convention of
-    nerf_helpers_acc.py), 'dense' with z [S] or [R,S] (render_volume_density convention)."""
+    nerf_helpers_acc.py), 'dense' with z [S] or [R,S] (render_volume_density convention), 'stratified' (dense convention
+    with randomize_depth(linspace(t_near, t_far, S)) drawn in the kernel from Philox (jitter_seed, jitter_stream))."""
     n_rays: int
     n_samples: int
     origins: Optional[torch.Tensor] = None
@@ -49,6 +50,8 @@ class RenderSpec:
     t_near: float = 0.0
     t_far: float = 0.0
     z: Optional[torch.Tensor] = None
+    jitter_seed: int = 0          # mode 'stratified': Philox stream of the in-kernel randomize_depth draw
+    jitter_stream: int = 0
 
 
 class Engine:
@@ -205,8 +208,11 @@ class Engine:
                 raise ValueError(f"z: shape {tuple(z.shape)}, expected [S] or [R,S]")
             keep.append(z)
             a.z = z.data_ptr()
+        elif spec.mode == "stratified":
+            a.depth_mode, a.t_near, a.t_far = _lib.DEPTH_STRATIFIED, float(spec.t_near), float(spec.t_far)
+            a.jitter_seed, a.jitter_stream = int(spec.jitter_seed), int(spec.jitter_stream)
         else:
-            raise ValueError(f"mode {spec.mode!r}: expected 'acc' or 'dense'")
+            raise ValueError(f"mode {spec.mode!r}: expected 'acc', 'dense' or 'stratified'")
         a.pixel = pixel.data_ptr()
         if sigma is not None:
             a.sigma = sigma.data_ptr()
@@ -352,3 +358,127 @@ def fine_depths(z_coarse, w_coarse, u):
     _lib.check(lib.afx_fine_depths(_ptr(z_coarse), int(z_coarse.dim() == 2), _ptr(w_coarse), _ptr(u), r, s, nf, _ptr(out),
                                    Engine._stream(dev)), "afx_fine_depths")
     return out
+
+
+# ---- occupancy grid / ray marching / device ray sampler (no model) ---------------------------------------------
+def _grid_desc(roi_aabb, resolution) -> "_lib.GridDesc":
+    g = _lib.GridDesc()
+    for i, v in enumerate([float(x) for x in roi_aabb]):
+        g.roi_aabb[i] = v
+    for i, v in enumerate([int(x) for x in resolution]):
+        g.resolution[i] = v
+    return g
+
+
+def philox_uniform(seed: int, stream_id: int, n: int, device) -> torch.Tensor:
+    """n uniform [0,1) numbers of the counter-based stream (seed, stream_id) - the generator of every perf-mode draw."""
+    lib = _lib.load()
+    out = torch.empty(int(n), dtype=torch.float32, device=device)
+    _lib.check(lib.afx_philox_uniform(int(seed), int(stream_id), int(n), _ptr(out), Engine._stream(out.device)), "afx_philox_uniform")
+    return out
+
+
+def grid_points(roi_aabb, resolution, cell_idx, n, jitter=None, seed=0, stream_id=0, device=None):
+    lib = _lib.load()
+    dev = device if device is not None else (cell_idx.device if cell_idx is not None else jitter.device)
+    if torch.device(dev).type != "cuda":
+        raise AfxError("grid_points: the occupancy grid lives on a GPU; there is no CPU fallback")
+    g = _grid_desc(roi_aabb, resolution)
+    pts = torch.empty(int(n), 3, dtype=torch.float32, device=dev)
+    if jitter is not None:
+        jitter = _f32(jitter, "jitter", pts.device)
+    _lib.check(lib.afx_grid_points(C.byref(g), _ptr(cell_idx), int(n), _ptr(jitter), int(seed), int(stream_id), _ptr(pts),
+                                   Engine._stream(pts.device)), "afx_grid_points")
+    return pts
+
+
+def grid_update(roi_aabb, resolution, occs, cell_idx, occ_new, ema_decay, scratch):
+    lib = _lib.load()
+    g = _grid_desc(roi_aabb, resolution)
+    occ_new = _f32(occ_new.reshape(-1), "occ_new", occs.device)
+    _lib.check(lib.afx_grid_update(C.byref(g), _ptr(occs), _ptr(scratch), _ptr(cell_idx), occ_new.numel(), _ptr(occ_new),
+                                   float(ema_decay), Engine._stream(occs.device)), "afx_grid_update")
+
+
+def grid_binarize(roi_aabb, resolution, occs, occ_thre, binary_u8, bits, partial_ws):
+    lib = _lib.load()
+    g = _grid_desc(roi_aabb, resolution)
+    _lib.check(lib.afx_grid_binarize(C.byref(g), _ptr(occs), float(occ_thre), _ptr(binary_u8), _ptr(bits), _ptr(partial_ws),
+                                     Engine._stream(occs.device)), "afx_grid_binarize")
+
+
+def march(origins, dirs, scene_aabb, near_plane, far_plane, step, grid_bits=None, grid_aabb=None, grid_res=None, want_points=True):
+    """Grid-skipping fixed-step march -> packed (ray_indices int32 [n], t_starts [n], t_ends [n], mid-points [n,3] | None,
+    offsets int64 [R+1])."""
+    lib = _lib.load()
+    dev = origins.device
+    if dev.type != "cuda":
+        raise AfxError("march: rays must live on a GPU; there is no CPU fallback")
+    o, d = _f32(origins, "origins", dev), _f32(dirs, "dirs", dev)
+    m = _lib.MarchArgs()
+    m.origins, m.dirs, m.n_rays = o.data_ptr(), d.data_ptr(), o.shape[0]
+    if scene_aabb is not None:
+        m.has_aabb = 1
+        for i, v in enumerate([float(x) for x in scene_aabb]):
+            m.scene_aabb[i] = v
+    if near_plane is not None:
+        m.has_near, m.near_plane = 1, float(near_plane)
+    if far_plane is not None:
+        m.has_far, m.far_plane = 1, float(far_plane)
+    m.step = float(step)
+    if grid_bits is not None:
+        m.grid_bits = grid_bits.data_ptr()
+        m.grid = _grid_desc(grid_aabb, grid_res)
+    st = Engine._stream(dev)
+    counts = torch.empty(o.shape[0], dtype=torch.int32, device=dev)
+    _lib.check(lib.afx_march_count(C.byref(m), _ptr(counts), st), "afx_march_count")
+    offsets = torch.zeros(o.shape[0] + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(counts, 0, out=offsets[1:])
+    n = int(offsets[-1])
+    ri = torch.empty(n, dtype=torch.int32, device=dev)
+    ts, te = torch.empty(n, device=dev), torch.empty(n, device=dev)
+    pts = torch.empty(n, 3, device=dev) if want_points else None
+    if n > 0:
+        _lib.check(lib.afx_march_write(C.byref(m), _ptr(offsets), _ptr(ri), _ptr(ts), _ptr(te), _ptr(pts), st), "afx_march_write")
+    return ri, ts, te, pts, offsets
+
+
+def march_visibility(raw, ts, te, offsets, early_stop_eps, alpha_thre, is_alpha=False):
+    """nerfacc render_visibility on the candidates' raw MLP outputs -> compacted (ray_indices, t_starts, t_ends)."""
+    lib = _lib.load()
+    dev = ts.device
+    n_rays = offsets.numel() - 1
+    raw = _f32(raw.reshape(-1), "raw", dev)
+    keep = torch.empty(ts.numel(), dtype=torch.uint8, device=dev)
+    counts = torch.empty(n_rays, dtype=torch.int32, device=dev)
+    st = Engine._stream(dev)
+    _lib.check(lib.afx_march_visibility(_ptr(raw), int(bool(is_alpha)), _ptr(ts), _ptr(te), _ptr(offsets), n_rays, float(early_stop_eps),
+                                        float(alpha_thre), _ptr(keep), _ptr(counts), st), "afx_march_visibility")
+    off2 = torch.zeros(n_rays + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(counts, 0, out=off2[1:])
+    n2 = int(off2[-1])
+    ri2 = torch.empty(n2, dtype=torch.int32, device=dev)
+    ts2, te2 = torch.empty(n2, device=dev), torch.empty(n2, device=dev)
+    if n2 > 0:
+        _lib.check(lib.afx_march_compact(_ptr(keep), _ptr(offsets), _ptr(off2), n_rays, _ptr(ts), _ptr(te), _ptr(ri2), _ptr(ts2),
+                                         _ptr(te2), st), "afx_march_compact")
+    return ri2, ts2, te2
+
+
+def sample_rays(origins, dirs, pixels, weights, k, u=None, seed=0, stream_id=0):
+    """Weighted sample WITHOUT replacement of k rows of a device-resident ray table (sample_pixel_rays, nerf_helpers.py:137-150):
+    Efraimidis-Spirakis keys log(u)/w, top-k on the device, gather.  Returns (origins[k,3], dirs[k,3], pixels[k] | None, idx)."""
+    lib = _lib.load()
+    dev = origins.device
+    if dev.type != "cuda":
+        raise AfxError("sample_rays: the ray table must live on a GPU; there is no CPU fallback")
+    n = origins.shape[0]
+    keys = torch.empty(n, device=dev)
+    st = Engine._stream(dev)
+    _lib.check(lib.afx_sample_keys(_ptr(weights), n, _ptr(u), int(seed), int(stream_id), _ptr(keys), st), "afx_sample_keys")
+    idx = torch.topk(keys, int(k), sorted=True).indices      # (order of the top-k = a random order of the sample: keys are i.i.d.)
+    o, d = torch.empty(int(k), 3, device=dev), torch.empty(int(k), 3, device=dev)
+    p = torch.empty(int(k), device=dev) if pixels is not None else None
+    _lib.check(lib.afx_gather_rays(_ptr(origins), _ptr(dirs), _ptr(pixels), _ptr(idx), int(k), _ptr(o), _ptr(d), _ptr(p), st),
+               "afx_gather_rays")
+    return o, d, p, idx

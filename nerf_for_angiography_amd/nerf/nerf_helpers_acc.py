@@ -12,8 +12,8 @@ def acc_ray_marching(radiance_field, grid, scene_aabb, ray_origins, ray_directio
 
     grid=None and scene_aabb=None: every ray is marched with the fixed step (far-near)/depth_samples_per_ray from
     near_thresh, no pruning (the dense variant of model/nerf_helpers_acc.py:29).  Otherwise the occupancy-grid march
-    of nerf/occupancy.py (restated nerfacc 0.3.x; parity unpinned) with the reference's alpha_fn: sigmoid density at
-    the interval mid-point, alpha = 1 - exp(-sigma * dt)."""
+    of nerf/occupancy.py (nerfacc 0.3.x's published algorithm on HIP kernels; parity unpinned) with the reference's
+    alpha_fn: sigmoid density at the interval mid-point, alpha = 1 - exp(-sigma * dt)."""
     render_step_size = (far_thresh - near_thresh) / depth_samples_per_ray
     if grid is None and scene_aabb is None:
         dev = ray_origins.device
@@ -24,13 +24,11 @@ def acc_ray_marching(radiance_field, grid, scene_aabb, ray_origins, ray_directio
         ray_indices = torch.arange(n_rays, dtype=torch.int32, device=dev).repeat_interleave(depth_samples_per_ray)
         return ray_indices, t_s.repeat(n_rays)[:, None], t_e.repeat(n_rays)[:, None]
 
-    def alpha_fn(t_starts, t_ends, ray_indices):
-        positions = ray_origins[ray_indices] + ray_directions[ray_indices] * (t_starts + t_ends) / 2.0
-        sigmas = torch.sigmoid(radiance_field(positions))
-        return 1 - torch.exp(-sigmas * (t_ends - t_starts))
-
+    # alpha_fn of the reference (nerf_helpers_acc.py:11-25): sigmoid density at the interval mid-point,
+    # alpha = 1 - exp(-sigma * dt).  The march kernel emits the mid-points, the visibility kernel forms alpha from the
+    # raw MLP output: only the fused MLP launch sits between the two.
     from .occupancy import ray_marching
-    return ray_marching(ray_origins, ray_directions, scene_aabb=scene_aabb, grid=grid, alpha_fn=alpha_fn,
+    return ray_marching(ray_origins, ray_directions, scene_aabb=scene_aabb, grid=grid, raw_fn=radiance_field,
                         near_plane=near_thresh, far_plane=far_thresh, early_stop_eps=early_stop_eps,
                         alpha_thre=alpha_thre, render_step_size=render_step_size)
 

@@ -1,9 +1,11 @@
 """Occupancy-grid acceleration — the part of nerfacc 0.3.x the reference uses (nerf/run_nerf_acc.py:196-198,284-287;
-nerf/nerf_helpers_acc.py:10-31,65-78; visualization/visualization.py:214).
+nerf/nerf_helpers_acc.py:10-31,65-78; visualization/visualization.py:214), on the HIP kernels of
+csrc/afx_kernels_grid.hip (include/afx.h: afx_grid_*, afx_march_*).
 
-nerfacc is a third-party CUDA package that the reference neither vendors nor pins and that is absent here, so this
-is a restatement of its PUBLISHED algorithm (0.3.x line: `OccupancyGrid`, `ContractionType.AABB`, `ray_marching`,
-`render_visibility`) — PARITY UNPINNED: no reference output exists to compare with.  Semantics kept:
+nerfacc is a third-party CUDA package that the reference neither vendors nor pins and that is absent here, so this is
+its PUBLISHED algorithm (0.3.x line: `OccupancyGrid`, `ContractionType.AABB`, `ray_marching`, `render_visibility`) —
+PARITY UNPINNED: no reference output exists to compare with; oracle/angio_oracle.py restates the same semantics on
+the CPU for the tests.  Semantics kept:
 
   OccupancyGrid(roi_aabb, resolution=128): `occs` float [res^3], `binary` bool [res,res,res];
     every_n_step(step, occ_eval_fn, occ_thre=1e-2, ema_decay=0.95, warmup_steps=256, n=16): every n-th training step
@@ -11,14 +13,20 @@ is a restatement of its PUBLISHED algorithm (0.3.x line: `OccupancyGrid`, `Contr
     num_cells/4 uniformly drawn cells plus num_cells/4 drawn among the occupied ones),
     occs[i] = max(occs[i] * ema_decay, occ), binary = occs > min(mean(occs), occ_thre).
   ray_marching: t range = ray/AABB intersection clipped to [near, far]; fixed-step lattice t_min + k*dt;
-    a step is kept when the cell containing its mid-point is occupied; with alpha_fn, steps with
-    alpha < alpha_thre or transmittance (exclusive product of 1-alpha over the ray's kept steps) < early_stop_eps
-    are dropped.  Returns packed, ray-sorted (ray_indices, t_starts[n,1], t_ends[n,1]).
+    a step is kept when the cell containing its mid-point is occupied; with alpha_fn, render_visibility:
+    steps with alpha < alpha_thre are skipped (they do not attenuate the transmittance), the ray ends once the
+    transmittance over its kept steps falls below early_stop_eps.  Returns packed, ray-sorted
+    (ray_indices, t_starts[n,1], t_ends[n,1]).
 
-The MLP evaluations inside (occ_eval_fn / alpha_fn) run in the fused HIP MLP kernel through the model's forward."""
+The grid lives on the GPU (there is no CPU fallback).  Randomness: which cells are refreshed is a torch draw (an index
+list is data); the jitter inside a cell is drawn in the kernel from the counter-based Philox stream (seed, step) unless
+the caller passes `jitter` (parity tests)."""
 from __future__ import annotations
 
 import torch
+
+from .. import engine as _engine
+from .._lib import AfxError
 
 
 class ContractionType:
@@ -28,20 +36,23 @@ class ContractionType:
 class OccupancyGrid(torch.nn.Module):
     NUM_DIM = 3
 
-    def __init__(self, roi_aabb, resolution=128, contraction_type=ContractionType.AABB):
+    def __init__(self, roi_aabb, resolution=128, contraction_type=ContractionType.AABB, seed: int = 0):
         super().__init__()
         if contraction_type != ContractionType.AABB:
             raise NotImplementedError("only ContractionType.AABB is used by the reference")
         res = [resolution] * 3 if isinstance(resolution, int) else list(resolution)
-        self.register_buffer("_roi_aabb", torch.as_tensor(roi_aabb, dtype=torch.float32).flatten())
+        self.register_buffer("_roi_aabb", torch.as_tensor(roi_aabb, dtype=torch.float32).flatten().clone())
         self.register_buffer("resolution", torch.tensor(res, dtype=torch.int32))
         self.num_cells = int(res[0] * res[1] * res[2])
         self.register_buffer("occs", torch.zeros(self.num_cells))
-        self.register_buffer("_binary", torch.zeros(res, dtype=torch.bool))
-        g = torch.stack(torch.meshgrid([torch.arange(r) for r in res], indexing="ij"), -1).reshape(-1, 3)
-        self.register_buffer("grid_coords", g)
-        self.register_buffer("grid_indices", torch.arange(self.num_cells))
+        self.register_buffer("_binary_u8", torch.zeros(self.num_cells, dtype=torch.uint8))
+        self.register_buffer("_bits", torch.zeros((self.num_cells + 31) // 32, dtype=torch.int32))      # packed bitfield for the march
+        self.register_buffer("_scratch", torch.zeros(self.num_cells))
+        self.register_buffer("_partial", torch.zeros(256, dtype=torch.float64))
+        self._aabb_host = [float(x) for x in self._roi_aabb.tolist()]
+        self._res_host = [int(x) for x in res]
         self.contraction_type = contraction_type
+        self.seed = int(seed)
 
     @property
     def roi_aabb(self):
@@ -49,29 +60,37 @@ class OccupancyGrid(torch.nn.Module):
 
     @property
     def binary(self):
-        return self._binary
+        return self._binary_u8.view(*self._res_host).bool()
+
+    @property
+    def bits(self):
+        return self._bits
+
+    def _require_gpu(self):
+        if not self.occs.is_cuda:
+            raise AfxError("OccupancyGrid: move the grid to the GPU (.to(device)); there is no CPU fallback")
 
     @torch.no_grad()
     def _sample_uniform_and_occupied_cells(self, n):
         uniform = torch.randint(self.num_cells, (n,), device=self.occs.device)
-        occupied = torch.nonzero(self._binary.flatten())[:, 0]
+        occupied = torch.nonzero(self._binary_u8)[:, 0]
         if n < len(occupied):
             occupied = occupied[torch.randint(len(occupied), (n,), device=self.occs.device)]
         return torch.cat([uniform, occupied], dim=0)
 
     @torch.no_grad()
-    def _update(self, step, occ_eval_fn, occ_thre=0.01, ema_decay=0.95, warmup_steps=256):
+    def _update(self, step, occ_eval_fn, occ_thre=0.01, ema_decay=0.95, warmup_steps=256, jitter=None):
+        self._require_gpu()
         if step < warmup_steps:
-            indices = self.grid_indices
+            indices, n = None, self.num_cells
         else:
-            indices = self._sample_uniform_and_occupied_cells(self.num_cells // 4)
-        coords = self.grid_coords[indices]
-        x = (coords + torch.rand_like(coords, dtype=torch.float32)) / self.resolution
-        lo, hi = self._roi_aabb[:3], self._roi_aabb[3:]
-        x = x * (hi - lo) + lo                                     # un-contract (AABB): unit cube -> world
-        occ = occ_eval_fn(x).reshape(-1)
-        self.occs[indices] = torch.maximum(self.occs[indices] * ema_decay, occ)
-        self._binary = (self.occs > torch.clamp(self.occs.mean(), max=occ_thre)).view(self._binary.shape)
+            indices = self._sample_uniform_and_occupied_cells(self.num_cells // 4).to(torch.int32).contiguous()
+            n = indices.numel()
+        x = _engine.grid_points(self._aabb_host, self._res_host, indices, n, jitter=jitter, seed=self.seed, stream_id=int(step),
+                                device=self.occs.device)
+        occ = occ_eval_fn(x).reshape(-1).float().contiguous()
+        _engine.grid_update(self._aabb_host, self._res_host, self.occs, indices, occ, ema_decay, self._scratch)
+        _engine.grid_binarize(self._aabb_host, self._res_host, self.occs, occ_thre, self._binary_u8, self._bits, self._partial)
 
     @torch.no_grad()
     def every_n_step(self, step, occ_eval_fn, occ_thre=1e-2, ema_decay=0.95, warmup_steps=256, n=16):
@@ -83,75 +102,36 @@ class OccupancyGrid(torch.nn.Module):
     @torch.no_grad()
     def query_occ(self, samples):
         """Occupancy (0/1) at world points [P,3]; points outside the ROI are empty (visualization.py:214)."""
-        idx, inside = _cell_index(samples, self._roi_aabb, self.resolution)
+        lo, hi = self._roi_aabb[:3], self._roi_aabb[3:]
+        u = (samples - lo) / (hi - lo)
+        inside = ((u >= 0) & (u < 1)).all(-1)
+        res = self.resolution.to(samples.device)
+        ijk = torch.minimum((u * res).floor().long().clamp(min=0), (res - 1).long())
+        idx = (ijk[:, 0] * res[1] + ijk[:, 1]) * res[2] + ijk[:, 2]
         out = torch.zeros(samples.shape[0], dtype=torch.bool, device=samples.device)
-        out[inside] = self._binary.flatten()[idx[inside]]
+        out[inside] = self._binary_u8[idx[inside]].bool()
         return out
-
-
-def _cell_index(pts, aabb, resolution):
-    lo, hi = aabb[:3], aabb[3:]
-    u = (pts - lo) / (hi - lo)
-    inside = ((u >= 0) & (u < 1)).all(-1)
-    res = resolution.to(pts.device)
-    ijk = torch.minimum((u * res).floor().long().clamp(min=0), (res - 1).long())
-    return (ijk[:, 0] * res[1] + ijk[:, 1]) * res[2] + ijk[:, 2], inside
-
-
-@torch.no_grad()
-def ray_aabb_intersect(rays_o, rays_d, aabb):
-    """Slab test -> (t_min, t_max); rays that miss get t_min = t_max = 1e10 (nerfacc's convention)."""
-    inv = 1.0 / torch.where(rays_d == 0, torch.full_like(rays_d, 1e-12), rays_d)
-    t0, t1 = (aabb[:3] - rays_o) * inv, (aabb[3:] - rays_o) * inv
-    tmin = torch.minimum(t0, t1).amax(-1)
-    tmax = torch.maximum(t0, t1).amin(-1)
-    miss = tmax < torch.clamp(tmin, min=0)
-    tmin, tmax = torch.clamp(tmin, min=0), tmax
-    return torch.where(miss, torch.full_like(tmin, 1e10), tmin), torch.where(miss, torch.full_like(tmax, 1e10), tmax)
 
 
 @torch.no_grad()
 def ray_marching(rays_o, rays_d, scene_aabb=None, grid=None, alpha_fn=None, near_plane=None, far_plane=None,
-                 early_stop_eps=1e-4, alpha_thre=0.0, render_step_size=1e-3):
-    n_rays, dev = rays_o.shape[0], rays_o.device
-    if scene_aabb is not None:
-        t_min, t_max = ray_aabb_intersect(rays_o, rays_d, scene_aabb)
+                 early_stop_eps=1e-4, alpha_thre=0.0, render_step_size=1e-3, raw_fn=None):
+    """nerfacc.ray_marching on the HIP kernels.  `alpha_fn(t_starts[n,1], t_ends[n,1], ray_indices[n]) -> alpha[n,1]` is the
+    upstream callback; `raw_fn(points[n,3]) -> raw[n,1]` is the short-cut the reference's alpha_fn reduces to (sigmoid
+    density at the interval mid-point): the mid-points come out of the march kernel and alpha is formed in the visibility
+    kernel, so nothing but the MLP launch sits between the two."""
+    if not rays_o.is_cuda:
+        raise AfxError("ray_marching: rays must live on a GPU; there is no CPU fallback")
+    aabb = None if scene_aabb is None else [float(x) for x in torch.as_tensor(scene_aabb).flatten().tolist()]
+    bits = grid.bits if grid is not None else None
+    ri, ts, te, pts, offsets = _engine.march(rays_o, rays_d, aabb, near_plane, far_plane, render_step_size, grid_bits=bits,
+                                             grid_aabb=None if grid is None else grid._aabb_host,
+                                             grid_res=None if grid is None else grid._res_host, want_points=raw_fn is not None)
+    if (alpha_fn is None and raw_fn is None) or ri.numel() == 0:
+        return ri, ts[:, None], te[:, None]
+    if raw_fn is not None:
+        vals, is_alpha = raw_fn(pts).reshape(-1).float(), False
     else:
-        t_min, t_max = torch.zeros(n_rays, device=dev), torch.full((n_rays,), 1e10, device=dev)
-    if near_plane is not None:
-        t_min = torch.clamp(t_min, min=near_plane)
-    if far_plane is not None:
-        t_max = torch.clamp(t_max, max=far_plane)
-    dt = float(render_step_size)
-    n_steps = torch.clamp(torch.ceil((t_max - t_min) / dt), min=0).long()
-    n_steps = torch.where(t_min >= 1e10, torch.zeros_like(n_steps), n_steps)
-    max_steps = int(n_steps.max()) if n_rays > 0 else 0
-    k = torch.arange(max_steps, device=dev, dtype=torch.float32)
-    t_s = t_min[:, None] + k[None, :] * dt                        # fixed-step lattice per ray
-    t_e = t_s + dt
-    keep = k[None, :] < n_steps[:, None]
-    if grid is not None:
-        mid = rays_o[:, None, :] + rays_d[:, None, :] * ((t_s + t_e) * 0.5)[..., None]
-        idx, inside = _cell_index(mid.reshape(-1, 3), grid.roi_aabb, grid.resolution)
-        occ = torch.zeros(idx.shape[0], dtype=torch.bool, device=dev)
-        occ[inside] = grid.binary.flatten()[idx[inside]]
-        keep &= occ.view(n_rays, max_steps)
-    ray_indices = torch.arange(n_rays, device=dev)[:, None].expand(n_rays, max_steps)[keep]
-    t_starts, t_ends = t_s[keep][:, None], t_e[keep][:, None]
-    if alpha_fn is not None and ray_indices.numel() > 0:
-        alphas = alpha_fn(t_starts, t_ends, ray_indices.long()).reshape(-1)
-        # exclusive transmittance within each ray (packed, ray-sorted): cumulative sums of log(1-alpha) per segment
-        logt = torch.log(torch.clamp(1 - alphas, min=1e-30))
-        csum = torch.cumsum(logt, 0)
-        first = torch.ones_like(ray_indices, dtype=torch.bool)
-        first[1:] = ray_indices[1:] != ray_indices[:-1]
-        start_off = torch.zeros_like(csum)
-        seg_start = torch.nonzero(first)[:, 0]
-        base = torch.where(seg_start > 0, csum[(seg_start - 1).clamp(min=0)], torch.zeros_like(csum[seg_start]))
-        start_off = base[torch.cumsum(first.long(), 0) - 1]
-        trans = torch.exp(csum - logt - start_off)
-        vis = trans >= early_stop_eps
-        if alpha_thre > 0:
-            vis &= alphas >= alpha_thre
-        ray_indices, t_starts, t_ends = ray_indices[vis], t_starts[vis], t_ends[vis]
-    return ray_indices.to(torch.int32), t_starts, t_ends
+        vals, is_alpha = alpha_fn(ts[:, None], te[:, None], ri.long()).reshape(-1).float(), True
+    ri2, ts2, te2 = _engine.march_visibility(vals, ts, te, offsets, early_stop_eps, alpha_thre, is_alpha=is_alpha)
+    return ri2, ts2[:, None], te2[:, None]

@@ -4,8 +4,15 @@ loop :263-441) on the MI355X hot path.
 Same command-line flags, model dictionary, ray sampling (`sample_pixel_rays` with `distance_pixel_value`
 weights), BARF schedule, learning-rate decay, evaluation cadence, best-PSNR / vessel-PSNR checkpointing and
 early stopping.  Differences: the dataset comes from `load_data` (which the reference calls but never defines) or
-is synthesised in memory; marching is dense (no nerfacc occupancy grid); TensorBoard/pyvista outputs are replaced
-by a JSONL log; one training iteration is the fused `train_step_mse` (or render + autograd with --precision f32).
+is synthesised in memory; TensorBoard/pyvista outputs are replaced by a JSONL log.
+
+Two iteration bodies (--march): `dense` (default) is ONE fused launch per ray chunk (`train_step_mse`: ray -> samples ->
+MLP -> Beer-Lambert -> MSE -> backward; render + autograd with --precision f32); `grid` is the reference's own body,
+run_nerf_acc.py:284-306, call for call - acc_update_n_step, acc_ray_marching with the occupancy grid (HIP march /
+visibility kernels, nerf/occupancy.py), positions, get_predictions, acc_render_volume_density, mse_loss, backward.
+The training rays live on the GPU: one table (origins, directions, pixel, weight) built once, and every iteration's
+batch is drawn there (weighted sampling without replacement, `engine.sample_rays`); --host_sampler restores the
+reference's per-iteration pandas draw (`sample_pixel_rays`).
 
     python -m nerf_for_angiography_amd.nerf.run_nerf_acc --synthetic --n_iters 2000 --num_layers 4 --num_hidden_units 128
 """
@@ -23,8 +30,11 @@ import torch
 from ..engine import RenderSpec
 from ..model.CPPN import CPPN
 from ..phantomdata import dataset as ds
+from .. import engine as _engine
 from ..render import render_rays, train_step_mse
-from .nerf_helpers import sample_pixel_rays
+from .nerf_helpers import sample_pixel_rays, get_predictions
+from .nerf_helpers_acc import acc_ray_marching, acc_render_volume_density, acc_update_n_step
+from .occupancy import OccupancyGrid, ContractionType
 
 
 def build_parser():
@@ -47,8 +57,12 @@ def build_parser():
     p.add_argument('--sample_size', type=int, default=75, help='rays per dimension per iteration (75^2 = 5625)')
     p.add_argument('--depth_samples', type=int, default=300)
     p.add_argument('--pos_enc', default='none', choices=['none', 'barf', 'fourier'])
-    p.add_argument('--precision', default='f16', choices=['f32', 'bf16x3', 'bf16', 'f16'])
+    p.add_argument('--precision', default='f16s8', choices=['f32', 'bf16x3', 'bf16', 'f16', 'f16s8'],
+                   help='arithmetic of the training step (include/afx.h); f16s8 = f16 with the backward stash kept as bf8')
     p.add_argument('--eval_precision', default='f16', choices=['f32', 'bf16x3', 'bf16', 'f16'])
+    p.add_argument('--march', default='dense', choices=['dense', 'grid'],
+                   help='dense: fused fixed-step march (one launch per ray chunk); grid: the reference loop with the occupancy grid')
+    p.add_argument('--host_sampler', action='store_true', help="draw each batch with pandas on the host (the reference's sample_pixel_rays)")
     p.add_argument('--log_dir', default='runs/afx')
     p.add_argument('--seed', type=int, default=0)
     p.add_argument('--out_bias_init', type=float, default=-5.0,
@@ -125,19 +139,53 @@ def main(argv=None):
         coarse_model.output_linear[0].bias.fill_(args.out_bias_init)
     coarse_optimizer = torch.optim.Adam(list(coarse_model.parameters()), lr=coarse_lr)
 
+    # device-resident ray table (R13): built once; every batch is drawn and gathered on the GPU
+    tab_o, tab_d = cols(train_ray_df, 'ray_origins'), cols(train_ray_df, 'ray_directions')
+    tab_pix = torch.from_numpy(train_ray_df['pixel_value'].to_numpy()).float().to(device)
+    tab_w = torch.from_numpy(train_ray_df['distance_pixel_value'].to_numpy()).float().to(device)
+
+    # occupancy grid of the reference loop (run_nerf_acc.py:196-198); thresholds :68-70
+    early_stop_eps, alpha_thre = 1e-2, 1e-3
+    scene_aabb = torch.tensor([-outside, -outside, -outside, outside, outside, outside], dtype=torch.float32, device=device)
+    acc_grid = OccupancyGrid(roi_aabb=scene_aabb, resolution=128, contraction_type=ContractionType.AABB, seed=args.seed).to(device) \
+        if args.march == 'grid' else None
+    batch_size = 131072
+
     os.makedirs(args.log_dir, exist_ok=True)
     log = open(os.path.join(args.log_dir, 'train_log.jsonl'), 'a')
     highest_psnr, highest_iter, history = 0.0, 0, []
     new_lr_coarse = coarse_lr
+    loss_coarse = torch.tensor(float('nan'), device=device)
+    n_marched = 0
     t_last = time.time()
     for n_iter in range(n_iters + 1):
         coarse_model.train()
         if coarse_model.use_pos_enc == 'barf' and barf_start <= n_iter < barf_stop:
             coarse_model.update_barf_alpha(coarse_model.barf_alpha + barf_step_size, 'pts')
-        batch_origins, batch_directions, batch_pix_vals = sample_pixel_rays(train_ray_df, img_sample_size, device,
-                                                                           weights='distance_pixel_value')
+        if args.host_sampler:
+            batch_origins, batch_directions, batch_pix_vals = sample_pixel_rays(train_ray_df, img_sample_size, device,
+                                                                               weights='distance_pixel_value')
+        else:
+            batch_origins, batch_directions, batch_pix_vals, _ = _engine.sample_rays(tab_o, tab_d, tab_pix, tab_w, img_sample_size,
+                                                                                     seed=args.seed, stream_id=n_iter)
         coarse_optimizer.zero_grad()
-        if args.precision == 'f32':
+        if args.march == 'grid':
+            # the reference's iteration body, run_nerf_acc.py:284-306
+            with torch.no_grad():
+                acc_grid.train()
+                acc_grid = acc_update_n_step(acc_grid, coarse_model, n_iter, occ_thre=alpha_thre)
+                ray_indices, t_starts, t_ends = acc_ray_marching(coarse_model, acc_grid, scene_aabb, batch_origins, batch_directions,
+                                                                 depth_samples_per_ray_coarse, near_thresh, far_thresh,
+                                                                 early_stop_eps, alpha_thre)
+            if len(ray_indices) > 0:
+                positions = batch_origins[ray_indices.long()] + batch_directions[ray_indices.long()] * (t_starts + t_ends) / 2.0
+                predictions = get_predictions(coarse_model, positions, batch_size)
+                pred, _ = acc_render_volume_density(predictions, ray_indices, t_starts, t_ends, img_sample_size,
+                                                    depth_samples_per_ray_coarse)
+                loss_coarse = torch.nn.functional.mse_loss(pred, batch_pix_vals)
+                loss_coarse.backward()
+                n_marched += int(len(ray_indices))
+        elif args.precision == 'f32':
             pred = render_rays(coarse_model, batch_origins, batch_directions, depth_samples_per_ray_coarse, near_thresh,
                                far_thresh, mode='acc').rgb_map
             loss_coarse = torch.nn.functional.mse_loss(pred, batch_pix_vals)
@@ -146,7 +194,8 @@ def main(argv=None):
             loss_coarse, pred = train_step_mse(coarse_model, RenderSpec(
                 n_rays=img_sample_size, n_samples=depth_samples_per_ray_coarse, origins=batch_origins,
                 dirs=batch_directions, mode='acc', t_near=near_thresh, t_far=far_thresh), batch_pix_vals)
-        coarse_optimizer.step()
+        if args.march != 'grid' or len(ray_indices) > 0:      # (the reference steps only when the march kept samples, :293)
+            coarse_optimizer.step()
         new_lr_coarse = coarse_lr * (decay_rate ** (n_iter / decay_steps))
         for param_group in coarse_optimizer.param_groups:
             param_group['lr'] = new_lr_coarse
@@ -155,8 +204,15 @@ def main(argv=None):
             coarse_model.eval()
             keep, coarse_model.precision = coarse_model.precision, args.eval_precision
             with torch.no_grad():
-                test_pred = render_rays(coarse_model, test_origins, test_directions, depth_samples_per_ray_coarse,
-                                        near_thresh, far_thresh, mode='acc').rgb_map
+                if args.march == 'grid':          # run_nerf_acc.py:338-349
+                    ri_t, ts_t, te_t = acc_ray_marching(coarse_model, acc_grid, scene_aabb, test_origins, test_directions,
+                                                        depth_samples_per_ray_coarse, near_thresh, far_thresh, early_stop_eps, alpha_thre)
+                    pos_t = test_origins[ri_t.long()] + test_directions[ri_t.long()] * (ts_t + te_t) / 2.0
+                    test_pred, _ = acc_render_volume_density(get_predictions(coarse_model, pos_t, batch_size) if len(ri_t) else pos_t[:, :1],
+                                                             ri_t, ts_t, te_t, test_origins.shape[0], depth_samples_per_ray_coarse)
+                else:
+                    test_pred = render_rays(coarse_model, test_origins, test_directions, depth_samples_per_ray_coarse,
+                                            near_thresh, far_thresh, mode='acc').rgb_map
             coarse_model.precision = keep
             pred_img = torch.zeros_like(test_img)
             pred_img[test_x, test_y] = test_pred
@@ -165,7 +221,11 @@ def main(argv=None):
             vessel_psnr = float(-10. * torch.log10(torch.nn.functional.mse_loss(test_pred[vessel], test_img[test_x, test_y][vessel])))
             rec = dict(iter=n_iter, train_loss=float(loss_coarse), train_psnr=float(-10. * torch.log10(loss_coarse)),
                        test_psnr=psnr, test_vessel_psnr=vessel_psnr, lr=new_lr_coarse,
-                       barf_alpha=float(getattr(coarse_model, 'barf_alpha', 0.0)), sec=round(time.time() - t_last, 3))
+                       barf_alpha=float(getattr(coarse_model, 'barf_alpha', 0.0)), sec=round(time.time() - t_last, 3),
+                       it_per_s=round(display_every / max(time.time() - t_last, 1e-9), 1) if n_iter else 0.0,
+                       marched_samples_per_iter=(n_marched // max(display_every, 1)) if args.march == 'grid' else
+                       img_sample_size * depth_samples_per_ray_coarse)
+            n_marched = 0
             t_last = time.time()
             history.append(rec)
             log.write(json.dumps(rec) + "\n")

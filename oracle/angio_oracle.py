@@ -473,3 +473,100 @@ def project_volume_scipy(axes, values, o: Tensor, d: Tensor, z: Tensor, type_ct:
     else:
         w = torch.exp(-mu)
     return w.prod(-1).float()
+
+
+# --------------------------------------------------------------------------
+# K1/K2  occupancy grid + grid-skipping march.  nerf/run_nerf_acc.py:196-198,284-287,
+#        nerf/nerf_helpers_acc.py:10-31,65-78 -> nerfacc 0.3.x (OccupancyGrid, ray_marching,
+#        render_visibility).  nerfacc is absent (not vendored, not pinned): this restates its
+#        PUBLISHED algorithm.                                             (UNPINNED)
+# --------------------------------------------------------------------------
+
+def grid_cell_index(pts: Tensor, aabb: Tensor, res: Sequence[int]):
+    """(flat cell index, inside) of world points for an AABB-contracted grid."""
+    lo, hi = aabb[:3], aabb[3:]
+    u = (pts - lo) / (hi - lo)
+    inside = ((u >= 0) & (u < 1)).all(-1)
+    r = torch.tensor(list(res), dtype=torch.float32)
+    ijk = torch.minimum((u * r).floor().long().clamp(min=0), (r - 1).long())
+    return (ijk[:, 0] * int(res[1]) + ijk[:, 1]) * int(res[2]) + ijk[:, 2], inside
+
+
+def grid_jittered_points(cells: Tensor, jitter: Tensor, aabb: Tensor, res: Sequence[int]) -> Tensor:
+    """OccupancyGrid._update: x = (coords + u) / resolution, un-contracted to world space."""
+    r = [int(v) for v in res]
+    k = cells % r[2]
+    j = (cells // r[2]) % r[1]
+    i = cells // (r[2] * r[1])
+    coords = torch.stack([i, j, k], -1).float()
+    x = (coords + jitter) / torch.tensor(r, dtype=torch.float32)
+    return x * (aabb[3:] - aabb[:3]) + aabb[:3]
+
+
+def grid_update(occs: Tensor, cells: Tensor, occ_new: Tensor, ema_decay: float, occ_thre: float):
+    """occs[c] = max(occs[c] * decay, occ) (a cell drawn twice: max over its draws); binary = occs > min(mean, thre)."""
+    out = occs.clone()
+    dec = occs * ema_decay
+    out[cells] = dec[cells]
+    out = out.index_reduce(0, cells, occ_new.reshape(-1).clamp(min=0), "amax", include_self=True)
+    thr = min(float(out.double().mean()), occ_thre)
+    return out, out > thr
+
+
+def ray_aabb(o: Tensor, d: Tensor, aabb: Tensor):
+    inv = 1.0 / torch.where(d == 0, torch.full_like(d, 1e-12), d)
+    t0, t1 = (aabb[:3] - o) * inv, (aabb[3:] - o) * inv
+    tmin = torch.minimum(t0, t1).amax(-1)
+    tmax = torch.maximum(t0, t1).amin(-1)
+    miss = tmax < torch.clamp(tmin, min=0)
+    return torch.where(miss, torch.full_like(tmin, 1e10), torch.clamp(tmin, min=0)), torch.where(miss, torch.full_like(tmax, 1e10), tmax)
+
+
+def march_grid(o: Tensor, d: Tensor, scene_aabb: Optional[Tensor], near: Optional[float], far: Optional[float], dt: float,
+               binary: Optional[Tensor] = None, grid_aabb: Optional[Tensor] = None):
+    """Fixed-step lattice t_min + k dt over [t_min, t_max); a step is kept when the cell of its mid-point is occupied.
+    -> packed ray-sorted (ray_indices, t_starts, t_ends), plain Python loops (small cases only)."""
+    n = o.shape[0]
+    if scene_aabb is not None:
+        tmin, tmax = ray_aabb(o, d, scene_aabb)
+    else:
+        tmin, tmax = torch.zeros(n), torch.full((n,), 1e10)
+    if near is not None:
+        tmin = torch.clamp(tmin, min=near)
+    if far is not None:
+        tmax = torch.clamp(tmax, max=far)
+    dtf = torch.tensor(dt, dtype=torch.float32)
+    ri, ts, te = [], [], []
+    for r in range(n):
+        if float(tmin[r]) >= 1e10:
+            continue
+        ns = int(max(0.0, math.ceil(float((tmax[r] - tmin[r]) / dtf))))
+        k = torch.arange(ns, dtype=torch.float32)
+        s = tmin[r] + k * dtf
+        e = s + dtf
+        keep = torch.ones(ns, dtype=torch.bool)
+        if binary is not None and ns > 0:
+            mid = o[r][None, :] + d[r][None, :] * ((s + e) * 0.5)[:, None]
+            idx, inside = grid_cell_index(mid, grid_aabb, binary.shape)
+            keep = inside & binary.flatten()[idx]
+        ri.append(torch.full((int(keep.sum()),), r, dtype=torch.int64)); ts.append(s[keep]); te.append(e[keep])
+    cat = lambda xs, dt_: torch.cat(xs) if xs else torch.zeros(0, dtype=dt_)
+    return cat(ri, torch.int64), cat(ts, torch.float32), cat(te, torch.float32)
+
+
+def render_visibility(alphas: Tensor, ri: Tensor, early_stop_eps: float, alpha_thre: float) -> Tensor:
+    """nerfacc's render_visibility: per ray, in order: stop once T < eps; skip (without attenuating T) alpha < thre;
+    else keep and T *= 1 - alpha."""
+    keep = torch.zeros(alphas.shape[0], dtype=torch.bool)
+    T, cur = 1.0, -1
+    for i in range(alphas.shape[0]):
+        if int(ri[i]) != cur:
+            cur, T = int(ri[i]), torch.tensor(1.0)
+        if T < early_stop_eps:
+            continue
+        a = alphas[i]
+        if a < alpha_thre:
+            continue
+        keep[i] = True
+        T = T * (1.0 - a)
+    return keep

@@ -3,6 +3,8 @@ host layer, against golden vectors captured from the reference and against the C
 
 Tolerances: fp32 mode ("f32", exact-fp32 MFMA): 1e-5 relative L2 on MLP outputs / pixels, 1e-4 on
 gradients (north-star bar: 1e-4 on rendered projections and density grids)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -730,6 +732,20 @@ def test_hip_graph_capture_of_the_render_and_train_step(golden):
     assert rel_l2(fwd_eager.cpu().numpy(), pix_eager.cpu().numpy()) < 1e-6
 
 
+def test_training_driver_reference_loop_with_grid(tmp_path):
+    """--march grid: the reference's own iteration body (run_nerf_acc.py:284-306) on the HIP grid / march kernels, with the
+    device ray sampler: loss goes down and the march skips most of the empty volume."""
+    from nerf_for_angiography_amd.nerf.run_nerf_acc import main
+    out = main(["--synthetic", "--img_size", "20", "--number_angles", "1", "--limited_size", "90", "--n_iters", "160",
+                "--display_every", "80", "--sample_size", "16", "--depth_samples", "100", "--num_layers", "4",
+                "--num_hidden_units", "64", "--sampling_strategy", "segmentation", "--march", "grid", "--precision", "f16",
+                "--log_dir", str(tmp_path / "run")])
+    h = out["history"]
+    assert [r["iter"] for r in h] == [0, 80, 160]
+    assert h[-1]["train_loss"] < h[0]["train_loss"] and all(np.isfinite(r["test_psnr"]) for r in h)
+    assert 0 < h[-1]["marched_samples_per_iter"] < 256 * 100
+
+
 def test_training_driver_runs_and_checkpoints(tmp_path):
     """Mirror of nerf/run_nerf_acc.py on a tiny synthetic dataset: loss goes down, the best checkpoint has the
     reference's dictionary layout and reloads into a fresh CPPN; 300 samples/ray (the reference's setting,
@@ -859,6 +875,149 @@ def test_reference_loop_with_occupancy_grid():
     for k, p in m.named_parameters():
         if p.grad is not None:
             assert rel_l2(p.grad.cpu().numpy(), params[k].grad.numpy()) < 1e-4, k
+
+
+def test_grid_kernels_vs_oracle():
+    """afx_grid_points / afx_grid_update / afx_grid_binarize / afx_march_count+write / afx_march_visibility+compact against
+    the oracle's restatement of nerfacc 0.3.x: indices and cell decisions bit-exact, floats bit-exact where the same
+    single-precision operations are applied (jitter, alphas supplied: parity mode)."""
+    from oracle import angio_oracle as orc
+    from nerf_for_angiography_amd import engine as eng
+
+    def same(a, b, what, scale=None):      # floats: identical up to one unit in the last place of the operands' magnitude
+        a, b = a.cpu(), b.cpu()
+        assert a.shape == b.shape, what
+        diff = (a.double() - b.double()).abs()
+        tol = 1.2e-7 * (float(b.abs().max()) if scale is None else scale)
+        assert bool((diff <= tol).all()), (what, int((diff > tol).sum()), float(diff.max()))
+
+    g = torch.Generator().manual_seed(5)
+    aabb = torch.tensor([-100.0, -80, -100, 100, 120, 90])
+    res = (16, 12, 20)
+    nc = res[0] * res[1] * res[2]
+    # --- points of jittered cells, all cells and an index list with duplicates
+    jit = torch.rand(nc, 3, generator=g)
+    pts = eng.grid_points(aabb.tolist(), res, None, nc, jitter=jit.to(DEV), device=torch.device(DEV))
+    same(pts, orc.grid_jittered_points(torch.arange(nc), jit, aabb, res), "points", 220.0)
+    cells = torch.randint(nc, (1500,), generator=g)
+    cells[100:200] = cells[0:100]                                          # duplicates
+    pts2 = eng.grid_points(aabb.tolist(), res, cells.to(DEV, torch.int32), cells.numel(), jitter=jit[:1500].to(DEV))
+    same(pts2, orc.grid_jittered_points(cells, jit[:1500], aabb, res), "points (index list)", 220.0)
+    # --- update rule + binarisation
+    occs0 = torch.rand(nc, generator=g) * (torch.rand(nc, generator=g) < 0.3)
+    occ_new = torch.rand(1500, generator=g) * 0.8
+    occs_d = occs0.clone().to(DEV)
+    eng.grid_update(aabb.tolist(), res, occs_d, cells.to(DEV, torch.int32), occ_new.to(DEV), 0.95, torch.empty(nc, device=DEV))
+    want, want_bin = orc.grid_update(occs0, cells, occ_new, 0.95, 1e-2)
+    same(occs_d, want, "occs")
+    b8, bits = torch.zeros(nc, dtype=torch.uint8, device=DEV), torch.zeros((nc + 31) // 32, dtype=torch.int32, device=DEV)
+    eng.grid_binarize(aabb.tolist(), res, occs_d, 1e-2, b8, bits, torch.zeros(256, dtype=torch.float64, device=DEV))
+    assert torch.equal(b8.cpu().bool(), want_bin)
+    unpacked = ((bits.cpu().long()[:, None] >> torch.arange(32)) & 1).reshape(-1)[:nc].bool()
+    assert torch.equal(unpacked, want_bin)
+    # --- march: rays through, beside and missing the box; with and without the grid; near/far clipping
+    r = 300
+    o = torch.tensor([[0.0, 10.0, 1500.0]]).repeat(r, 1) + torch.randn(r, 3, generator=g) * 5
+    d = torch.nn.functional.normalize(torch.randn(r, 3, generator=g) * 0.08 + torch.tensor([0, 0, -1.0]), dim=-1)
+    d[7] = torch.tensor([0.0, 0.0, -1.0])                                   # a zero direction component
+    d[8] = torch.tensor([0.7, 0.7, -0.1])                                   # misses
+    binary = want_bin.view(*res)
+    for use_grid, near, far in ((False, 1400.0, 1600.0), (True, 1400.0, 1600.0), (True, None, 1700.0), (True, 1450.0, None)):
+        ri, ts, te, mid, off = eng.march(o.to(DEV), d.to(DEV), aabb.tolist(), near, far, 2.5, grid_bits=bits if use_grid else None,
+                                         grid_aabb=aabb.tolist(), grid_res=res)
+        ri_c, ts_c, te_c = orc.march_grid(o, d, aabb, near, far, 2.5, binary if use_grid else None, aabb)
+        assert torch.equal(ri.cpu().long(), ri_c), (use_grid, near, far)
+        same(ts, ts_c, "t_starts"); same(te, te_c, "t_ends")
+        assert torch.equal(off.cpu(), torch.cat([torch.zeros(1, dtype=torch.long), torch.bincount(ri_c, minlength=r).cumsum(0)]))
+        pos_c = o[ri_c] + d[ri_c] * (ts_c + te_c)[:, None] / 2.0
+        same(mid, pos_c, "mid-points", 1700.0)
+    # --- render_visibility on supplied alphas (parity mode) and through the raw path
+    alphas = torch.rand(ri_c.numel(), generator=g) * (torch.rand(ri_c.numel(), generator=g) < 0.7) * 0.6
+    for eps, thre in ((1e-2, 1e-3), (0.3, 0.0), (1e-4, 0.2)):
+        ri2, ts2, te2 = eng.march_visibility(alphas.to(DEV), ts, te, off, eps, thre, is_alpha=True)
+        keep = orc.render_visibility(alphas, ri_c, eps, thre)
+        assert torch.equal(ri2.cpu().long(), ri_c[keep]); same(ts2, ts_c[keep], "kept t_starts"); same(te2, te_c[keep], "kept t_ends")
+    raw = torch.randn(ri_c.numel(), generator=g) * 3
+    a_raw = 1 - torch.exp(-torch.sigmoid(raw) * (te_c - ts_c))
+    ri3, _, _ = eng.march_visibility(raw.to(DEV), ts, te, off, 1e-2, 1e-3)
+    keep3 = orc.render_visibility(a_raw, ri_c, 1e-2, 1e-3)
+    assert (ri3.cpu().long().numel() - int(keep3.sum())) in (-1, 0, 1)      # expf vs torch.exp at a threshold: at most one flip
+    # empty input
+    ri0, ts0, te0, _, off0 = eng.march(o[:0].to(DEV), d[:0].to(DEV), aabb.tolist(), 1400.0, 1600.0, 2.5)
+    assert ri0.numel() == 0 and off0.tolist() == [0]
+
+
+def test_device_ray_sampler_and_philox():
+    """R13 on the device: a resident ray table, weighted sampling without replacement (Efraimidis-Spirakis keys + top-k) and
+    the gather - no pandas, no host round trip per iteration; the Philox stream behind every perf-mode draw."""
+    from nerf_for_angiography_amd import engine as eng
+    dev = torch.device(DEV)
+    u = eng.philox_uniform(7, 3, 100000, dev)
+    assert torch.equal(u, eng.philox_uniform(7, 3, 100000, dev)) and not torch.equal(u[:1000], eng.philox_uniform(7, 4, 1000, dev))
+    assert float(u.min()) >= 0.0 and float(u.max()) < 1.0 and abs(float(u.mean()) - 0.5) < 5e-3 and abs(float(u.var()) - 1 / 12) < 2e-3
+    assert torch.equal(u[:10], eng.philox_uniform(7, 3, 10, dev))            # counter-based: a prefix is a prefix
+    n, k = 20000, 512
+    g = torch.Generator().manual_seed(2)
+    o, d, pix = torch.randn(n, 3, generator=g).to(DEV), torch.randn(n, 3, generator=g).to(DEV), torch.rand(n, generator=g).to(DEV)
+    w = torch.rand(n, generator=g)
+    w[:n // 2] *= 0.02                                                      # first half nearly never drawn
+    w[5] = 0.0
+    uu = torch.rand(n, generator=g).clamp(min=1e-7)
+    so, sd, sp, idx = eng.sample_rays(o, d, pix, w.to(DEV), k, u=uu.to(DEV))
+    keys = torch.where(w > 0, torch.log(uu) / w, torch.full_like(w, -float("inf")))
+    assert set(idx.cpu().tolist()) == set(torch.topk(keys, k).indices.tolist())
+    assert idx.unique().numel() == k and 5 not in idx.cpu().tolist()        # without replacement; zero weight never drawn
+    assert torch.equal(so, o[idx]) and torch.equal(sd, d[idx]) and torch.equal(sp, pix[idx])
+    frac_low = []
+    for step in range(20):                                                  # perf mode: Philox keys, one stream per step
+        _, _, _, idx = eng.sample_rays(o, d, pix, w.to(DEV), k, seed=11, stream_id=step)
+        frac_low.append(float((idx < n // 2).float().mean()))
+    assert 0.005 < float(np.mean(frac_low)) < 0.05                          # expected share of the down-weighted half ~ 2 %
+
+
+def test_stratified_depths_fused():
+    """R4: (a) parity mode - the reference-captured stratified depths of fixture G3 fed through the fused kernel (dense
+    convention, shared z) against the oracle; (b) perf mode - randomize_depth drawn IN the kernel from Philox equals the
+    host formula on the same uniform numbers."""
+    from oracle import angio_oracle as orc
+    from nerf_for_angiography_amd import engine as eng
+    from nerf_for_angiography_amd.render import render_rays, render_spec
+    from nerf_for_angiography_amd.engine import RenderSpec
+    from nerf_for_angiography_amd.phantomdata.proj_helpers import source_matrix
+    g3 = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "g3_stratify.npz")))
+    torch.manual_seed(4)
+    m = make_model(4, 128)
+    with torch.no_grad():
+        m.output_linear[0].weight.mul_(4.0)
+        m.output_linear[0].bias.fill_(-26.0)
+    pose = source_matrix(np.array([0, 0, 1500.0]), 60.0, 15.0)
+    o_all, d_all = orc.get_rays(pose, 48, 48, 13.0 * 48)
+    pick = torch.randperm(48 * 48)[:700]
+    o, d = o_all.reshape(-1, 3)[pick].float(), d_all.reshape(-1, 3)[pick].float()
+    cfg = dict(num_early_layers=4, num_filters=128)
+    params = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    for s in (32, 128):
+        z = torch.from_numpy(g3[f"out{s}"]) * 200.0 + 1400.0               # the reference's jittered depths, scaled to the scene
+        assert torch.equal(orc.stratify(torch.from_numpy(g3[f"z{s}"]), torch.from_numpy(g3[f"u{s}"])), torch.from_numpy(g3[f"out{s}"]))
+        pix_c = orc.render_rays(o, d, cfg, params, near=0.0, far=0.0, n_samples=s, z=z, convention="dense")
+        with torch.no_grad():
+            pix = render_rays(m, o.to(DEV), d.to(DEV), mode="dense", z=z.to(DEV)).rgb_map
+        assert float(pix_c.max()) > 1e-3 and rel_l2(pix.cpu().numpy(), pix_c.numpy()) < 1e-5, s
+    # perf mode
+    s, near, far = 64, 1400.0, 1600.0
+    u = eng.philox_uniform(99, 5, s, torch.device(DEV)).cpu()
+    t = torch.arange(s, dtype=torch.float32) / (s - 1)
+    z_lin = near * (1.0 - t) + far * t
+    z_host = orc.stratify(z_lin, u)
+    spec = RenderSpec(n_rays=o.shape[0], n_samples=s, origins=o.to(DEV), dirs=d.to(DEV), mode="stratified", t_near=near, t_far=far,
+                      jitter_seed=99, jitter_stream=5)
+    with torch.no_grad():
+        a = render_spec(spec, m).rgb_map
+        b = render_rays(m, o.to(DEV), d.to(DEV), mode="dense", z=z_host.to(DEV)).rgb_map
+        spec.jitter_stream = 6
+        c = render_spec(spec, m).rgb_map
+    assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
+    assert rel_l2(c.cpu().numpy(), b.cpu().numpy()) > 1e-6                  # another stream, another jitter
 
 
 @pytest.mark.parametrize("layers,width,n_samples,n_rays", [(1, 64, 2, 1), (2, 128, 33, 7), (12, 64, 32, 40), (3, 256, 5, 3),

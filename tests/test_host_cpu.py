@@ -235,49 +235,60 @@ def test_acc_helpers_host_paths():
     assert na.acc_update_n_step(None, None, 0) is None
 
 
-def test_occupancy_grid_march_properties():
-    """Restated nerfacc 0.3.x semantics (parity unpinned): grid update rule, grid skipping on the fixed-step lattice,
-    early termination and alpha threshold, packed ray-sorted output."""
-    from nerf_for_angiography_amd.nerf.occupancy import OccupancyGrid, ray_marching, ray_aabb_intersect
-    from nerf_for_angiography_amd.nerf import nerf_helpers_acc as na
+def test_occupancy_grid_march_oracle_properties():
+    """The oracle's restatement of nerfacc 0.3.x (parity unpinned): grid update rule, grid skipping on the fixed-step
+    lattice, render_visibility (alpha threshold skips without attenuating, early termination), packed ray-sorted
+    output.  The product runs these on HIP kernels (tests/test_gpu_parity.py compares the two)."""
+    from oracle import angio_oracle as orc
     torch.manual_seed(0)
     aabb = torch.tensor([-100.0, -100, -100, 100, 100, 100])
-    grid = OccupancyGrid(roi_aabb=aabb, resolution=16)
-    ball = lambda x: (x.norm(dim=-1, keepdim=True) < 40).float() * 0.5          # dense ball of radius 40
-    for step in range(0, 64, 16):
-        grid.every_n_step(step, ball, occ_thre=1e-2)
-    assert grid.binary.shape == (16, 16, 16) and 0.03 < grid.binary.float().mean() < 0.25
-    assert bool(grid.query_occ(torch.tensor([[0.0, 0, 0]]))[0]) and not bool(grid.query_occ(torch.tensor([[90.0, 90, 90], [500.0, 0, 0]])).any())
-    grid.eval()
-    with pytest.raises(RuntimeError):
-        grid.every_n_step(0, ball)
+    res = (16, 16, 16)
+    occs = torch.zeros(16 ** 3)
+    ball = lambda x: (x.norm(dim=-1) < 40).float() * 0.5          # dense ball of radius 40
+    for step in range(4):
+        cells = torch.arange(16 ** 3)
+        pts = orc.grid_jittered_points(cells, torch.rand(cells.numel(), 3), aabb, res)
+        occs, binary = orc.grid_update(occs, cells, ball(pts), 0.95, 1e-2)
+    assert 0.03 < binary.float().mean() < 0.25
+    idx, inside = orc.grid_cell_index(torch.tensor([[0.0, 0, 0], [90.0, 90, 90], [500.0, 0, 0]]), aabb, res)
+    assert bool(binary[idx[0]]) and not bool(binary[idx[1]]) and not bool(inside[2])
+    # a cell drawn twice takes the max over its draws, from the decayed OLD value
+    o2, _ = orc.grid_update(torch.tensor([1.0, 0.2]), torch.tensor([0, 0, 1]), torch.tensor([0.3, 0.99, 0.1]), 0.5, 1e-2)
+    assert torch.allclose(o2, torch.tensor([0.99, 0.1]))
     o = torch.tensor([[0.0, 0.0, 1500.0]]).repeat(3, 1)
     d = torch.tensor([[0.0, 0.0, -1.0], [0.02, 0.0, -1.0], [0.5, 0.5, -1.0]])
-    tmin, tmax = ray_aabb_intersect(o, d, aabb)
+    tmin, tmax = orc.ray_aabb(o, d, aabb)
     assert abs(float(tmin[0]) - 1400) < 1e-3 and abs(float(tmax[0]) - 1600) < 1e-3 and float(tmin[2]) == 1e10
-    ri, ts, te = ray_marching(o, d, scene_aabb=aabb, grid=None, near_plane=1400.0, far_plane=1600.0, render_step_size=2.0)
+    ri, ts, te = orc.march_grid(o, d, aabb, 1400.0, 1600.0, 2.0)
     assert int((ri == 0).sum()) == 100 and int((ri == 2).sum()) == 0            # dense inside the box, miss -> nothing
-    ri, ts, te = ray_marching(o, d, scene_aabb=aabb, grid=grid, near_plane=1400.0, far_plane=1600.0, render_step_size=2.0)
-    mid0 = ((ts + te) / 2)[ri == 0, 0]
+    ri, ts, te = orc.march_grid(o, d, aabb, 1400.0, 1600.0, 2.0, binary.view(*res), aabb)
+    mid0 = ((ts + te) / 2)[ri == 0]
     assert 30 <= mid0.numel() <= 60 and float(mid0.min()) > 1440 and float(mid0.max()) < 1560   # only the ball's cells
     assert torch.all(ri[1:] >= ri[:-1]) and torch.allclose(te - ts, torch.full_like(ts, 2.0))
-    # early termination: a very dense medium stops after a few steps; alpha threshold removes thin samples
-    dense = lambda ts, te, ri: torch.full((ts.shape[0], 1), 0.9)
-    ri2, _, _ = ray_marching(o[:1], d[:1], scene_aabb=aabb, grid=grid, alpha_fn=dense, near_plane=1400.0, far_plane=1600.0,
-                             early_stop_eps=2e-2, render_step_size=2.0)
-    assert ri2.numel() == 2                                                      # exclusive T = 1, 0.1, 0.01 (< eps): two steps kept
-    thin = lambda ts, te, ri: torch.full((ts.shape[0], 1), 1e-4)
-    ri3, _, _ = ray_marching(o[:1], d[:1], scene_aabb=aabb, grid=grid, alpha_fn=thin, near_plane=1400.0, far_plane=1600.0,
-                             alpha_thre=1e-3, render_step_size=2.0)
-    assert ri3.numel() == 0
-    # through the reference-shaped wrapper
-    class Const(torch.nn.Module):
-        def forward(self, x):
-            return torch.full((x.shape[0], 1), 3.0)
-    ri4, ts4, te4 = na.acc_ray_marching(Const(), grid, aabb, o, d, 100, 1400.0, 1600.0)
-    assert ri4.dtype == torch.int32 and ts4.shape == te4.shape == (ri4.numel(), 1) and 0 < ri4.numel() < 20
-    grid.train()
-    assert na.acc_update_n_step(grid, Const(), 16) is grid
+    # render_visibility: T = 1, 0.1, 0.01 (< eps): two steps kept; thin samples are skipped and do not attenuate
+    ri1 = torch.zeros(6, dtype=torch.int64)
+    assert orc.render_visibility(torch.full((6,), 0.9), ri1, 2e-2, 0.0).tolist() == [True, True, False, False, False, False]
+    assert orc.render_visibility(torch.full((6,), 1e-4), ri1, 1e-4, 1e-3).sum() == 0
+    mixed = torch.tensor([1e-4, 0.9, 1e-4, 0.9, 0.9, 0.9])
+    assert orc.render_visibility(mixed, ri1, 2e-2, 1e-3).tolist() == [False, True, False, True, False, False]
+    # two rays in one packed list: T restarts
+    assert orc.render_visibility(torch.full((4,), 0.95), torch.tensor([0, 0, 1, 1]), 0.1, 0.0).tolist() == [True, False, True, False]
+
+
+def test_occupancy_product_refuses_cpu():
+    from nerf_for_angiography_amd.nerf.occupancy import OccupancyGrid, ray_marching
+    from nerf_for_angiography_amd.nerf import nerf_helpers_acc as na
+    from nerf_for_angiography_amd._lib import AfxError
+    grid = OccupancyGrid(roi_aabb=torch.tensor([-1.0, -1, -1, 1, 1, 1]), resolution=8)
+    assert grid.binary.shape == (8, 8, 8) and grid.bits.numel() == 16
+    with pytest.raises(AfxError, match="no CPU fallback"):
+        grid.every_n_step(0, lambda x: x[:, :1])
+    with pytest.raises(AfxError, match="no CPU fallback"):
+        ray_marching(torch.zeros(2, 3), torch.ones(2, 3), far_plane=1.0)
+    grid.eval()
+    with pytest.raises(RuntimeError):
+        grid.every_n_step(0, lambda x: x[:, :1])
+    assert na.acc_update_n_step(None, None, 0) is None
 
 
 def test_bench_flop_model():
