@@ -11,6 +11,16 @@ def rev_sigmoid(x, c1=1, c2=0):
     return 1 / (1 + np.exp(c1 * (x - c2)))
 
 
+# knots of the CT transfer function (helpers.py:33-70): HU-like value -> attenuation, piecewise linear, clamped at both ends
+_TF_X = (0.0, 753.0, 1585.85, 2332.9, 3306.18, 4000.0)
+_TF_Y = {False: (0.0, 0.0, 0.05, 0.0, 0.2, 0.4), True: (0.0, 0.0, 0.0, 0.0, 0.2, 0.4)}
+
+
+def transfer_func_ct(vals, binary=False, cathlab=False):
+    """helpers.py:33-70: the manual "x-ray" transfer function (binary: vessels only)."""
+    return np.interp(np.asarray(vals, dtype=np.float64), _TF_X, _TF_Y[bool(binary)])
+
+
 def get_ray_values(theta, phi, larm, src_pt, img_width, img_height, focal_length, device, translation=np.array([0, 0, 0])):
     """helpers.py:156-175 -> (ray_origins[H,W,3], ray_directions[H,W,3], src_matrix, ii, jj), float64."""
     src_matrix = source_matrix(src_pt, theta, phi, larm, translation)

@@ -476,6 +476,28 @@ def project_volume_scipy(axes, values, o: Tensor, d: Tensor, z: Tensor, type_ct:
 
 
 # --------------------------------------------------------------------------
+# transfer functions of the phantom generators.  phantomdata/helpers.py:17-18 (rev_sigmoid), :20-31 (line),
+# :33-70 (transfer_func_ct)                                           (PINNED, G11; captured with a frangi stand-in)
+# --------------------------------------------------------------------------
+
+def rev_sigmoid(x, c1: float = 1.0, c2: float = 0.0):
+    return 1.0 / (1.0 + np.exp(c1 * (np.asarray(x, dtype=np.float64) - c2)))
+
+
+def transfer_func_ct(vals, binary: bool = False):
+    """Six knots, straight lines between them written as m*x + b (helpers.py:20-31), constants outside."""
+    xs = [0.0, 753.0, 1585.85, 2332.9, 3306.18, 4000.0]
+    ys = [0.0, 0.0, 0.0 if binary else 0.05, 0.0, 0.2, 0.4]
+    v = np.asarray(vals, dtype=np.float64)
+    out = np.where(v < xs[0], ys[0], np.where(v >= xs[-1], ys[-1], 0.0))
+    for (x1, y1), (x2, y2) in zip(zip(xs[:-1], ys[:-1]), zip(xs[1:], ys[1:])):
+        m, b0 = (y1 - y2) / (x1 - x2), (x1 * y2 - x2 * y1) / (x1 - x2)
+        seg = (v >= x1) & (v < x2)
+        out = np.where(seg, m * v + b0, out)
+    return out
+
+
+# --------------------------------------------------------------------------
 # K1/K2  occupancy grid + grid-skipping march.  nerf/run_nerf_acc.py:196-198,284-287,
 #        nerf/nerf_helpers_acc.py:10-31,65-78 -> nerfacc 0.3.x (OccupancyGrid, ray_marching,
 #        render_visibility).  nerfacc is absent (not vendored, not pinned): this restates its

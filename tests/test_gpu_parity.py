@@ -805,6 +805,20 @@ def test_voxel_projector_vs_scipy(type_ct):
         VoxelVolume(np.array([0.0, 1.0, 3.0]), t, t, np.zeros((3, 41, 41)), device=DEV)
 
 
+def test_voxel_projector_vs_reference_fixture(golden):
+    """afx_project_volume against the REFERENCE's ray_tracing output (fixture G10, captured with a frangi stand-in for the
+    one import this container lacks): 41^3 voxelised sphere + capsule, 64 x 48 detector, two poses, both branches."""
+    from nerf_for_angiography_amd.phantomdata.helpers import VoxelVolume, ray_tracing
+    g = golden("g10_ray_tracing")
+    w, h, f = (int(g["whf"][0]), int(g["whf"][1]), float(g["whf"][2]))
+    vol = VoxelVolume(g["axis"], g["axis"], g["axis"], g["mu"], fill_value=float(g["fill"]), device=DEV)
+    for tag in ("a", "b"):
+        o, d, z = T(g[f"{tag}_o"]), T(g[f"{tag}_d"]), T(g[f"{tag}_z"])
+        for kind in ("ct", "sdf"):
+            got = ray_tracing(vol, list(g[f"{tag}_angles"]), o, d, z, w, h, None, None, 32, DEV, None, type=kind)
+            assert rel_l2(got.cpu().numpy(), g[f"{tag}_img_{kind}"]) < 1e-5, (tag, kind)      # fp32 ray arrays into the kernel
+
+
 def test_two_stream_overlap_mode_matches_serial(monkeypatch):
     """AFX_OVERLAP=1 (weight-gradient kernels of chunk i on a side stream while the chain kernel of chunk i+1 runs,
     double-buffered stash, non-persistent chain grid) must give the same gradients as the serial schedule."""

@@ -176,3 +176,32 @@ def test_g9_density_grid(golden):
     sd = sd_of(g)
     grid = orc.density_grid(lambda p: orc.cppn_forward(p, _c1_cfg(), sd), 100.0, 16)
     assert rel_l2(grid.numpy(), g["sigma"]) < 1e-6
+
+
+def test_g10_ray_tracing(golden):
+    """R14: the reference's ray_tracing output on a voxelised analytic phantom (captured with a frangi stand-in for the one
+    import the container lacks) vs the oracle's projector, both branches, two poses; and R2 once more through helpers.py."""
+    g = golden("g10_ray_tracing")
+    w, h, f = g["whf"]
+    ax = g["axis"]
+    for tag in ("a", "b"):
+        th, ph, la = g[f"{tag}_angles"]
+        pose = orc.source_matrix(np.array([0, 0, 1500.0]), th, ph, la)
+        assert np.array_equal(pose, g[f"{tag}_pose"])
+        o, d = orc.get_rays(pose, int(w), int(h), float(f))
+        assert np.array_equal(o.float().numpy(), g[f"{tag}_o"]) and np.array_equal(d.float().numpy(), g[f"{tag}_d"])
+        z = T(g[f"{tag}_z"])
+        for kind, ct in (("ct", True), ("sdf", False)):
+            img = orc.project_volume_scipy((ax, ax, ax), g["mu"], o.reshape(-1, 3), d.reshape(-1, 3), z, ct, fill_value=float(g["fill"]))
+            # the fixture stores the volume in fp32, the reference interpolated the float64 original: 1e-6, not 1e-7
+            assert rel_l2(img.reshape(int(h), int(w)).numpy(), g[f"{tag}_img_{kind}"]) < 2e-6, (tag, kind)
+
+
+def test_g11_transfer_functions(golden):
+    from nerf_for_angiography_amd.phantomdata import helpers as ph
+    g = golden("g11_transfer")
+    for binary, key in ((False, "tf"), (True, "tf_binary")):
+        assert np.allclose(orc.transfer_func_ct(g["vals"], binary), g[key], rtol=0, atol=1e-15)
+        assert np.allclose(ph.transfer_func_ct(g["vals"], binary=binary), g[key], rtol=0, atol=1e-12)
+    assert np.array_equal(orc.rev_sigmoid(g["x"], 2.0), g["rev_sigmoid_c1_2"]) and np.array_equal(orc.rev_sigmoid(g["x"]), g["rev_sigmoid_default"])
+    assert np.array_equal(ph.rev_sigmoid(g["x"], c1=2), g["rev_sigmoid_c1_2"])
