@@ -76,3 +76,31 @@ class GradSync:
     @staticmethod
     def uninstall():
         _render._grad_hook = None
+
+
+def density_grid_sharded(model, outside: float, n: int, group=None) -> torch.Tensor:
+    """The reconstructed 3-D density grid (visualization/visualization.py:100-102,209-229; layout as render.density_grid:
+    grid[i,j,k] = sigma(t[j], t[i], t[k]), t = linspace(-outside, outside, n+1)) computed by all ranks: each evaluates the
+    MLP on its contiguous range of the (n+1)^3 points, one all-gather assembles the full grid on every rank.
+    Points are generated from their flat index, so no rank materialises the whole point list."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    m = n + 1
+    total = m * m * m
+    start, count = shard(total, rank, world)
+    dev = model.flat_params.device if getattr(model, "flat_params", None) is not None else next(model.parameters()).device
+    t = torch.linspace(-outside, outside, m, dtype=torch.float64, device=dev).float()
+    idx = torch.arange(start, start + count, device=dev)
+    i, j, k = idx // (m * m), (idx // m) % m, idx % m
+    pts = torch.stack([t[j], t[i], t[k]], -1).contiguous()
+    with torch.no_grad():
+        sig = torch.sigmoid(model(pts)).reshape(-1) if count > 0 else torch.zeros(0, device=dev)
+    if world == 1:
+        return sig.reshape(m, m, m)
+    per = (total + world - 1) // world + 1                      # equal-size slots for the collective
+    slot = torch.zeros(per, device=dev)
+    slot[:count] = sig
+    gathered = torch.empty(world * per, device=dev)
+    dist.all_gather_into_tensor(gathered, slot, group=group)
+    parts = [gathered[r * per:r * per + shard(total, r, world)[1]] for r in range(world)]
+    return torch.cat(parts).reshape(m, m, m)

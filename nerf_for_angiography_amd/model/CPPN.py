@@ -284,46 +284,49 @@ class CPPN(nn.Module):
         return self.output_linear(values)
 
     def pos_enc(self, values, pos_enc_basis, type):
+        """[x, enc_sin(x tiled L times), enc_cos(...)] (model/CPPN.py:207-214); the fused kernels evaluate the same terms."""
         if pos_enc_basis <= 0:
             return values
-        basis_values = torch.cat(pos_enc_basis * [values], dim=-1)
-        return torch.cat([values] + self.enc_fun(basis_values, type), dim=-1)
+        tiled = values.repeat(*([1] * (values.dim() - 1)), pos_enc_basis)        # x, y, z, x, y, z, ...
+        waves = self.enc_fun(tiled, type)
+        return torch.cat((values, *waves), dim=-1)
+
+    def _enc_tables(self, type):
+        views = type == "views"
+        if self.use_pos_enc == "fourier":
+            return (self.fourier_coefficients_views if views else self.fourier_coefficients), None
+        return (self.barf_freq_views if views else self.barf_freq), (self.barf_weights_views if views else self.barf_weights)
 
     def fourier_pos_enc(self, values, type):
-        coefficients = self.fourier_coefficients_views if type == "views" else self.fourier_coefficients
-        value = 2 * np.pi * values * coefficients
-        return [torch.sin(value), torch.cos(value)]
+        """sin / cos of 2 pi x c with learnable c ~ N(0, sigma^2) (model/CPPN.py:216-222)."""
+        coeff, _ = self._enc_tables(type)
+        phase = 2 * np.pi * values * coeff
+        return [phase.sin(), phase.cos()]
 
     def barf_pos_enc(self, values, type):
-        if type == "views":
-            value, weights = self.barf_freq_views.to(values.device) * values, self.barf_weights_views
-        else:
-            value, weights = self.barf_freq.to(values.device) * values, self.barf_weights
+        """w_k sin / cos(2^k pi x) with the coarse-to-fine weights w_k of update_barf_alpha (model/CPPN.py:224-234)."""
+        freq, weights = self._enc_tables(type)
+        phase = freq.to(values.device) * values
         weights = weights.to(values.device)
-        return [weights * torch.sin(value), weights * torch.cos(value)]
+        return [weights * phase.sin(), weights * phase.cos()]
 
     def update_barf_alpha(self, barf_alpha, type):
+        """Advance the coarse-to-fine schedule (model/CPPN.py:236-242)."""
         if type == "views":
-            self.barf_alpha_views = barf_alpha
-            self.barf_weights_views = self.barf_coefficients(barf_alpha, self.k_values_views)
+            self.barf_alpha_views, self.barf_weights_views = barf_alpha, self.barf_coefficients(barf_alpha, self.k_values_views)
         else:
-            self.barf_alpha = barf_alpha
-            self.barf_weights = self.barf_coefficients(barf_alpha, self.k_values)
+            self.barf_alpha, self.barf_weights = barf_alpha, self.barf_coefficients(barf_alpha, self.k_values)
 
     def barf_coefficients(self, barf_alpha, k_values):
-        """Coarse-to-fine weights, literal incl. the 3.1415 constant and the (alpha - k + 1) argument
-        (model/CPPN.py:244-259).  Returned as a fresh nn.Parameter (D8) so that
-        state_dict()['barf_weights'] exists, but frozen: it is a schedule, not a weight."""
-        weights = []
-        for k in k_values:
-            g = barf_alpha - (k + 1)
-            if g < 0:
-                weights.append(0.0)
-            elif g < 1:
-                weights.append(float((1 - torch.cos((barf_alpha - k + 1) * 3.1415)) / 2))
-            else:
-                weights.append(1.0)
-        return nn.Parameter(torch.tensor(weights, dtype=torch.float32), requires_grad=False)
+        """Coarse-to-fine weight per frequency band k for progress alpha (model/CPPN.py:244-259): 0 before the band opens
+        (alpha < k + 1), 1 once it is fully open (alpha >= k + 2), a raised-cosine ramp in between - literal incl. the
+        3.1415 constant and the (alpha - k + 1) argument of the ramp.  Returned as a fresh nn.Parameter (D8) so
+        that state_dict()['barf_weights'] exists, but frozen: it is a schedule, not a weight."""
+        k = torch.as_tensor(k_values, dtype=torch.float32)
+        opened = barf_alpha - (k + 1)
+        ramp = (1 - torch.cos((barf_alpha - k + 1) * 3.1415)) / 2
+        w = torch.where(opened < 0, torch.zeros_like(k), torch.where(opened < 1, ramp, torch.ones_like(k)))
+        return nn.Parameter(w.to(torch.float32), requires_grad=False)
 
     def save(self, filename: str, training_information: dict) -> None:
         """Same checkpoint dictionary as the reference (model/CPPN.py:261-276)."""

@@ -23,25 +23,22 @@ def transfer_func_ct(vals, binary=False, cathlab=False):
 
 def get_ray_values(theta, phi, larm, src_pt, img_width, img_height, focal_length, device, translation=np.array([0, 0, 0])):
     """helpers.py:156-175 -> (ray_origins[H,W,3], ray_directions[H,W,3], src_matrix, ii, jj), float64."""
+    from .._geometry import camera_rays
     src_matrix = source_matrix(src_pt, theta, phi, larm, translation)
-    tform = torch.from_numpy(src_matrix).to(device)
-    ii, jj = torch.meshgrid(torch.arange(0, img_width).to(tform), torch.arange(0, img_height).to(tform), indexing='xy')
-    directions = torch.stack([(ii - img_width / 2) / focal_length, -(jj - img_height / 2) / focal_length,
-                              -torch.ones_like(ii)], dim=-1)
-    ray_directions = torch.sum(directions[..., None, :] * tform[:3, :3], dim=-1).to(device)
-    ray_origins = tform[:3, -1].expand(ray_directions.shape).to(device)
+    pose = torch.from_numpy(src_matrix).to(device)
+    cols = torch.arange(img_width, dtype=pose.dtype, device=pose.device)
+    rows = torch.arange(img_height, dtype=pose.dtype, device=pose.device)
+    ii, jj = cols[None, :].expand(img_height, img_width), rows[:, None].expand(img_height, img_width)      # 'xy' meshgrid: [H, W]
+    ray_origins, ray_directions = camera_rays(pose, ii, jj, img_width, img_height, focal_length)
     return ray_origins, ray_directions, src_matrix, ii, jj
 
 
 def get_depth_values(near_thresh, far_thresh, depth_samples_per_ray, device, stratified=True):
     """helpers.py:177-190."""
-    t_vals = torch.linspace(0., 1., depth_samples_per_ray)
-    z_vals = near_thresh * (1. - t_vals) + far_thresh * t_vals
+    from .._geometry import uniform_depths, jitter_depths
+    z_vals = uniform_depths(near_thresh, far_thresh, depth_samples_per_ray)
     if stratified:
-        mids = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
-        upper = torch.cat([mids, z_vals[..., -1:]], -1)
-        lower = torch.cat([z_vals[..., :1], mids], -1)
-        z_vals = lower + (upper - lower) * torch.rand(z_vals.shape)
+        z_vals = jitter_depths(z_vals, torch.rand(z_vals.shape))
     return z_vals.to(device)
 
 

@@ -44,17 +44,12 @@ def source_matrix(source_pt, theta, phi, larm=0, translation=[0, 0, 0], type='ro
 def get_query_points(x, y, img_width, img_height, focal_length, tform_cam2world, depth_samples_per_ray,
                      near_thresh, far_thresh, device, randomize=False):
     """proj_helpers.py:9-32 -> (query_points, ray_origins, ray_directions, depth_values); d is not normalised."""
-    direction = torch.stack([(x - img_width * .5) / focal_length, -(y - img_height * .5) / focal_length,
-                             -torch.ones_like(x)], dim=-1).to(device)
-    ray_directions = torch.sum(direction[..., None, :] * tform_cam2world[:3, :3], dim=-1)
-    ray_origins = tform_cam2world[:3, -1].expand(ray_directions.shape).to(device)
-    t_vals = torch.linspace(0., 1., depth_samples_per_ray)
-    z_vals = near_thresh * (1. - t_vals) + far_thresh * t_vals
+    from .._geometry import camera_rays, uniform_depths, jitter_depths
+    ray_origins, ray_directions = camera_rays(tform_cam2world, x.to(tform_cam2world), y.to(tform_cam2world), img_width,
+                                              img_height, focal_length)
+    ray_origins, ray_directions = ray_origins.to(device), ray_directions.to(device)
+    depth_values = uniform_depths(near_thresh, far_thresh, depth_samples_per_ray)
     if randomize:
-        mids = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
-        upper = torch.cat([mids, z_vals[..., -1:]], -1)
-        lower = torch.cat([z_vals[..., :1], mids], -1)
-        z_vals = lower + (upper - lower) * torch.rand(z_vals.shape)
-    depth_values = z_vals.to(ray_origins.device)
-    query_points = ray_origins[..., None, :] + ray_directions[..., None, :] * depth_values[..., :, None]
-    return query_points, ray_origins, ray_directions, depth_values
+        depth_values = jitter_depths(depth_values, torch.rand(depth_values.shape))
+    depth_values = depth_values.to(ray_origins.device)
+    return ray_origins.unsqueeze(-2) + ray_directions.unsqueeze(-2) * depth_values.unsqueeze(-1), ray_origins, ray_directions, depth_values

@@ -819,6 +819,42 @@ def test_voxel_projector_vs_reference_fixture(golden):
             assert rel_l2(got.cpu().numpy(), g[f"{tag}_img_{kind}"]) < 1e-5, (tag, kind)      # fp32 ray arrays into the kernel
 
 
+def test_evaluation_sweep(golden):
+    """visualization.py:277-454 as two launches: every view of the angle sweep rendered in one fused call and compared with
+    the ground-truth projector's output over the same poses; PSNR / DOT 2D / DICE 2D per view against a per-view oracle."""
+    from oracle import angio_oracle as orc
+    from nerf_for_angiography_amd.visualization.sweep import sweep_angles, evaluation_sweep, ground_truth_sweep
+    from nerf_for_angiography_amd.phantomdata.helpers import VoxelVolume
+    assert sweep_angles(180, 5).shape == (37 * 37, 2)
+    g = golden("g10_ray_tracing")
+    vol = VoxelVolume(g["axis"], g["axis"], g["axis"], g["mu"], fill_value=float(g["fill"]), device=DEV)
+    angles = sweep_angles(40, 20)                       # 3 x 3 views
+    w, h, s = 24, 20, 48
+    near, far, src = 1400.0, 1600.0, np.array([0, 0, 1500.0])
+    z = torch.linspace(near, far, 96)
+    gt = ground_truth_sweep(vol, angles, w, h, 13.0 * w, src, z)
+    torch.manual_seed(8)
+    m = make_model(4, 64)
+    with torch.no_grad():
+        m.output_linear[0].weight.mul_(8.0)
+        m.output_linear[0].bias.fill_(-5.0)
+    df, preds = evaluation_sweep(m, gt, angles, w, h, 13.0 * w, src, near, far, s, binary_targets=(gt > 0.9).float())
+    assert list(df.columns[:9]) == ["image_id", "theta", "phi", "larm", "theta_360", "phi_360", "cam_pose_x", "cam_pose_y", "cam_pose_z"]
+    assert len(df) == 9 and df["theta_360"].min() >= 0 and preds.shape == (9, h, w)
+    cfg = dict(num_early_layers=4, num_filters=64)
+    params = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    for i, (th, ph) in enumerate(angles):
+        pose = orc.source_matrix(src, th if th >= 0 else 360 + th, ph if ph >= 0 else 360 + ph)
+        o, d = orc.get_rays(pose, w, h, 13.0 * w)
+        want_gt = orc.project_volume_scipy((g["axis"],) * 3, g["mu"], o.reshape(-1, 3), d.reshape(-1, 3), z.double(), True, float(g["fill"]))
+        assert rel_l2(gt[i].cpu().numpy().ravel(), want_gt.numpy()) < 1e-5
+        pix = orc.render_rays(o.reshape(-1, 3).float(), d.reshape(-1, 3).float(), cfg, params, near=near, far=far, n_samples=s, convention="acc")
+        assert rel_l2(preds[i].cpu().numpy().ravel(), pix.numpy()) < 1e-5
+        psnr = float(-10 * torch.log10(torch.mean((pix - want_gt) ** 2)))
+        assert abs(df["PSNR"][i] - psnr) < 1e-3
+    assert 0.0 <= df["DICE 2D"].min() <= df["DICE 2D"].max() <= 1.0 and df["DOT 2D"].between(0, 1).all()
+
+
 def test_two_stream_overlap_mode_matches_serial(monkeypatch):
     """AFX_OVERLAP=1 (weight-gradient kernels of chunk i on a side stream while the chain kernel of chunk i+1 runs,
     double-buffered stash, non-persistent chain grid) must give the same gradients as the serial schedule."""

@@ -186,39 +186,26 @@ def test_pose_and_ray_helpers_match_golden(golden):
 
 def test_nerf_helpers_host_paths_match_golden(golden):
     from nerf_for_angiography_amd.nerf import nerf_helpers as nh
+    from nerf_for_angiography_amd._lib import AfxError
     g3 = golden("g3_stratify")
     torch.manual_seed(100 + 32)
     assert np.array_equal(nh.randomize_depth(T(g3["z32"]), "cpu").numpy(), g3["out32"])
     g5 = golden("g5_render")
-    for rk in ("n", "tail", "c2", "c3"):
-        rgb, dep, w, ent, (sig, _) = nh.render_volume_density(T(g5["raw_" + rk]), T(g5["d"]), T(g5["z2"]))
-        for name, got in (("rgb", rgb), ("depth", dep), ("weights", w), ("entropy", ent), ("sigma", sig)):
-            np.testing.assert_allclose(got.numpy(), g5[f"{rk}_z2_{name}"], rtol=2e-6, atol=1e-30)
     np.testing.assert_allclose(nh.cumprod_exclusive(T(g5["cumprod_in"])).numpy(), g5["cumprod_out"], rtol=1e-7)
+    sig, rgb = T(g5["n_z2_sigma"]), T(g5["n_z2_rgb"])
+    np.testing.assert_allclose(nh.get_ray_entropy(sig, rgb).numpy(), g5["n_z2_entropy"], rtol=2e-6, atol=1e-30)
     g7 = golden("g7_sample_pdf")
     out = nh.sample_pdf(T(g7["a_bins"]), T(g7["a_w"]), 16, "cpu", u=T(g7["a_u"]))
     assert rel_l2(out.numpy(), g7["a_out"]) < 1e-7
     assert [b.shape[0] for b in nh.get_minibatches(torch.zeros(10, 3), 4)] == [4, 4, 2]
-
-
-def test_fine_sampling_restated_call_runs_on_host(golden):
-    """The upstream fine_sampling cannot run; the restated one does and returns 3 outputs."""
-    from nerf_for_angiography_amd.nerf import nerf_helpers as nh
-    from nerf_for_angiography_amd.model.CPPN import CPPN
-    from oracle import angio_oracle as orc
-    torch.manual_seed(0)
-    m = CPPN(model_def(4, 64))
-    r, s, nf = 12, 16, 8
-    o = torch.tensor([[0.0, 0.0, 1500.0]]).repeat(r, 1)
-    d = torch.nn.functional.normalize(torch.randn(r, 3) * 0.02 + torch.tensor([0, 0, -1.0]), dim=-1)
-    z = torch.linspace(1400.0, 1600.0, s)
-    w = torch.rand(r, s)
-    u = torch.rand(r, nf)
-    with torch.no_grad():
-        rgb, dep, ent = nh.fine_sampling(z, w, o, d, m, None, nf, 4096, u=u)
-    assert rgb.shape == (r,) and dep.shape == (r,) and ent.shape == (r,)
-    zf = orc.fine_depths(z, w, u, r)
-    assert zf.shape == (r, s + nf) and float((zf[:, 1:] - zf[:, :-1]).min()) >= 0
+    # compositing has no CPU fallback (the oracle holds the maths, tests/test_oracle_golden.py pins it to G5) and only the
+    # one-channel configuration the reference trains
+    with pytest.raises(AfxError, match="no CPU fallback"):
+        nh.render_volume_density(T(g5["raw_n"]), T(g5["d"]), T(g5["z2"]))
+    with pytest.raises(NotImplementedError):
+        nh.render_volume_density(T(g5["raw_c2"]), T(g5["d"]), T(g5["z2"]))
+    with pytest.raises(AfxError, match="no CPU fallback"):
+        nh.fine_sampling(torch.linspace(0, 1, 8), torch.rand(3, 8), torch.zeros(3, 3), torch.ones(3, 3), None, None, 4, 64)
 
 
 def test_acc_helpers_host_paths():
@@ -349,8 +336,14 @@ def _dp_worker(rank, world, port, q):
     start, count = afx_dist.shard(n, r, w)
     g = _dp_flat_grad(m, o[start:start + count], d[start:start + count], tgt[start:start + count], n)
     render._grad_hook(g)                          # what _RenderFn.backward / train_step_mse call: SUM over ranks
+    grid = afx_dist.density_grid_sharded(m, 100.0, 6)      # 7^3 = 343 points: unequal point ranges, one all-gather
     g_union = _dp_flat_grad(m, o, d, tgt, n) if rank == 0 else None      # the 1-rank gradient of the union batch
-    q.put((rank, flat0[:8].tolist(), g.tolist(), None if g_union is None else g_union.tolist(), start, count))
+    with torch.no_grad():
+        t = torch.linspace(-100.0, 100.0, 7, dtype=torch.float64).float()
+        gy, gx, gz = torch.meshgrid(t, t, t, indexing="ij")
+        want = torch.sigmoid(m(torch.stack([gx, gy, gz], -1).reshape(-1, 3))).reshape(7, 7, 7)
+    q.put((rank, flat0[:8].tolist(), g.tolist(), None if g_union is None else g_union.tolist(), start, count,
+           bool(torch.allclose(grid, want, atol=1e-6))))
     afx_dist.GradSync.uninstall()
     dist.destroy_process_group()
 
@@ -369,7 +362,8 @@ def test_two_rank_gloo_grad_sync_and_sharding():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (r0, w0, g0, u0, s0, c0), (r1, w1, g1, u1, s1, c1) = res
+    (r0, w0, g0, u0, s0, c0, d0), (r1, w1, g1, u1, s1, c1, d1) = res
+    assert d0 and d1                               # the sharded density grid equals the single-process grid on both ranks
     assert w0 == w1                                # rank 0's weights everywhere
     assert g0 == g1                                # identical synced gradients on both ranks
     assert (s0, c0, s1, c1) == (0, 19, 19, 18)
