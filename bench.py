@@ -55,9 +55,12 @@ def stash_bytes_per_sample(width, layers, precision, in_kernel_small=True):
     chain = wgrad + (3 * width + 8) * 4 / 32
     if precision == "f16s8":                              # one byte per stash element
         chain, wgrad = chain - wgrad + wgrad // 2, wgrad // 2
-    if precision in ("f16", "f16s8"):
+    if precision == "f16":
         chain += 4                                        # dL/draw per sample (the chain is normalised by it)
         wgrad += 4
+    if precision == "f16s8":
+        chain += 4 / 32                                   # one exponent per 32-sample group
+        wgrad += 4 / 32
     return chain, wgrad
 
 
@@ -86,7 +89,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--precision", default=os.environ.get("AFX_BENCH_PRECISION", "f16"), choices=["f32", "bf16x3", "bf16", "f16", "f16s8"])
+    ap.add_argument("--precision", default=os.environ.get("AFX_BENCH_PRECISION", "f16s8"), choices=["f32", "bf16x3", "bf16", "f16", "f16s8"])
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--samples", type=int, default=128)
     ap.add_argument("--layers", type=int, default=8)

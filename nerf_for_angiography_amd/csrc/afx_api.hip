@@ -575,6 +575,7 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
     const int bI = nbuf == 2 ? (int)(ci & 1) : 0;
     a.tile0 = (int)t0; a.tile1 = (int)t1;
     a.stash_h = stash_h[bI]; a.stash_dz = stash_dz[bI]; a.stash_e = stash_e[bI]; a.graw = graw[bI];
+    a.gexp = (int32_t*)graw[bI];       // 8-bit stash: dL/draw itself is not stashed; its slot holds the group exponents
     a.small_part = sg ? (float*)((char*)stash_h[bI] + (size_t)N * rows * F * esz) : nullptr;     // H_N's stash is not written then
     if (nbuf == 2 && ci >= 2) HIPCHK(hipStreamWaitEvent(st, c->ev_wgrad[bI], 0));     // buffer bI has been consumed
     a.gmax = h16 ? gmax_words + 16 * bI : nullptr;
@@ -602,7 +603,7 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
     rps = (rps + 63) / 64 * 64;        // whole 32-/64-sample stages
     w.rows_per_split = (int)rps;
     w.partial = partial; w.partial2 = partial2; w.partial_s = partial_s; w.debug = a.debug; w.small_groups = sg ? 1 : 0;
-    w.gmax = a.gmax; w.stash_esz = (int)esz; w.wout_perm = a.small + (size_t)(N + 1) * F;
+    w.gmax = a.gmax; w.stash_esz = (int)esz; w.gexp = a.gexp;
     ReduceArgs rd;
     rd.partial = partial; rd.partial2 = partial2; rd.n_hidden = N; rd.k0 = c->k0; rd.k0pad = k0ld; rd.n_splits = splits;
     rd.grad = grad_flat; rd.hidden_only = b16 ? 1 : 0; rd.partial_s = partial_s;

@@ -75,7 +75,8 @@ struct ChainArgs {
   // in-kernel small gradients (bf16 backward, rays mode, no encoding): per 32-sample group [SW[F] S0[F] S1[F] c[3] d[3] sum_g -]
   float* small_part;        // null: H_N, dZ_0, encoded inputs and dL/draw are stashed for k_small_grads_bf16 instead
   uint32_t* gmax;           // f16 mode: bit pattern of max |dL/draw| over the chunk (integer atomicMax; zeroed per chunk)
-  int32_t stash8;           // f16 mode: 8-bit (bf8) stash of H_l and J_l
+  int32_t stash8;           // f16 mode: 8-bit (bf8) stash of H_l and dZ'_l
+  int32_t* gexp;            // 8-bit stash: power-of-two exponent of each 32-sample group's largest |dL/draw| [rows/32]
 };
 
 struct WgradArgs {
@@ -94,7 +95,7 @@ struct WgradArgs {
   int32_t small_groups;     // 1: the chain kernel left per-group sums where H_N's stash would be (k_small_from_groups)
   const uint32_t* gmax;     // f16 mode: the chunk's max |dL/draw| (scale of the contraction, wgrad_scale_exp)
   int32_t stash_esz;        // bytes per stash element (4 f32, 2 bf16/f16, 1 bf8)
-  const float* wout_perm;   // 8-bit stash: permuted output weights in the prepared `small` section (layer-N row fix)
+  const int32_t* gexp;      // 8-bit stash: group exponents (block scales of the MX contraction)
 };
 
 struct ReduceArgs {

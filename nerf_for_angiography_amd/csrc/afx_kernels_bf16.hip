@@ -74,8 +74,9 @@ template <int F> __device__ __forceinline__ uint32_t stash_off(uint32_t r, int c
   return ((((r >> 5) * (F / 8) + ch) << 5) + (r & 31)) << 4;      // < 2^32: the host bounds a layer's stash
 }
 
-// S8 (8-bit stash, f16 mode): H_l and J_l are stashed as bf8 (e5m2: the top byte of the f16 pattern, same exponent
-// range, so H needs no scale; J is scaled by 2^AFX_S8_JSHIFT, its values sit around 1e-4..1).  A lane's 16 values of a
+// S8 (8-bit stash, f16 mode): H_l and dZ'_l = g_hat J_l are stashed as bf8 (e5m2: the top byte of the f16 pattern, same
+// exponent range, so H needs no scale; dZ' is scaled by 2^AFX_S8_JSHIFT, J sits around 1e-4..1 and |g_hat| <= 1: g of a
+// sample divided by the power of two of its 32-sample group's largest |g|, which travels as that group's block scale).  A lane's 16 values of a
 // tile are ONE 16-byte store: stash position p8 = 16 (2t + h) + 8 s + j for feature 32t + 16s + 8(j>>2) + 4h + (j&3);
 // layout [row>>5][p8>>4][row&31][16 B], so a wave store is again one contiguous 1 KiB run.  Half the bytes of the
 // 16-bit stash in both directions.
@@ -640,15 +641,27 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
     if (BWD) {
       // ---------------- input-gradient chain, 16-bit operands, fp32 accumulate.  bf16: dZ_l.  H16: J_l = dZ_l / g.
       u32x4 dz[NCG][NT][2];
+      unsigned ghat2[NCG];
 #pragma unroll
       for (int cg = 0; cg < NCG; ++cg) {
-        if ((H16 || !SG) && hh == 0) a.graw[m[cg]] = g[cg];
+        ghat2[cg] = 0;
+        if (((H16 && !S8) || !SG) && hh == 0) a.graw[m[cg]] = g[cg];
         if constexpr (H16) {
           float gm = fabsf(g[cg]);
 #pragma unroll
           for (int sh = 16; sh >= 1; sh >>= 1) gm = fmaxf(gm, __shfl_xor(gm, sh));
           // integer max of non-negative float bit patterns: order-independent, so the result is deterministic
           if (lane == 0 && gm > 0.f) atomicMax(a.gmax, __builtin_bit_cast(uint32_t, gm));
+          if constexpr (S8) {
+            // 8-bit stash: dZ' = g_hat J with g normalised by its 32-sample group's power of two, |g_hat| <= 1; the group's
+            // exponent goes to the weight-gradient kernel as the block scale of the MX matrix instruction
+            int eg = 0;
+            if (gm > 0.f) (void)frexpf(gm, &eg);
+            // (the 2^JSHIFT of the stash is folded in HERE: g_hat J alone would sink into f16's subnormals before the conversion)
+            const float gh = ldexpf(g[cg], AFX_S8_JSHIFT - eg);
+            ghat2[cg] = pack2h(gh, gh);
+            if (lane == 0) a.gexp[m[cg] >> 5] = eg;
+          }
         }
         const float gs = H16 ? 1.f : g[cg];
 #pragma unroll
@@ -668,8 +681,11 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
 #pragma unroll
         for (int cg = 0; cg < NCG; ++cg) {
           if constexpr (S8) {
+            const f16x2_t gh = __builtin_bit_cast(f16x2_t, ghat2[cg]);
+            const f16x8_t gh8 = {gh[0], gh[0], gh[0], gh[0], gh[0], gh[0], gh[0], gh[0]};
             stash_store((char*)a.stash_dz + (size_t)l * a.stash_rows * F + (so[cg] + (uint32_t)(2 * t) * 512u),
-                        to_bf8x16(dz[cg][t][0], dz[cg][t][1], 1.0f / (float)(1 << AFX_S8_JSHIFT)));
+                        to_bf8x16(__builtin_bit_cast(u32x4, __builtin_bit_cast(f16x8_t, dz[cg][t][0]) * gh8),
+                                  __builtin_bit_cast(u32x4, __builtin_bit_cast(f16x8_t, dz[cg][t][1]) * gh8), 1.0f));
           } else {
 #pragma unroll
             for (int s = 0; s < 2; ++s)
@@ -898,55 +914,34 @@ __global__ void __launch_bounds__(512) k_wgrad_bf16(const WgradArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Weight gradients from the 8-bit stash (f16 mode, S8): H_{l-1} and J_l 2^AFX_S8_JSHIFT as bf8, layout
-// [row>>5][p8>>4][row&31][16 B].  Same contraction as k_wgrad_bf16<F, true>:
-//   dW_l Ls 2^JSHIFT = sum_n (J_l[n][o] 2^JSHIFT) * (g_n Ls) H_{l-1}[n][i]
-// A 64-sample stage is 2 x F/16 LDS-DMA instructions (lane = stage row, 16 bytes); one ds_read_b64_tr_b8 delivers
-// the 8 samples x 1 position an MFMA operand lane needs as 8 bytes (lane 2q+p of a 16-lane group supplies row q,
-// bytes 8p..8p+7 of a 16-byte chunk; lane i receives byte i of the 8 rows), four v_cvt_scalef32_pk_f16_bf8 turn them
-// into the f16 fragment.  Chunk columns are padded to 1152 B: the two 16-lane groups of a half-wave read 128
-// contiguous bytes each, 32 banks apart.
-// Layer N: J_N = w_out * [H_N > 0] has one value per feature, whose bf8 rounding would be a SYSTEMATIC error of the
-// row; every non-zero byte decodes to the same number, so the A fragment (lane = feature) is rescaled by the per-lane
-// constant f16(w_out) 2^JSHIFT / decoded value, which restores f16(w_out) exactly where the mask is set.
-// ---------------------------------------------------------------------------------------
-typedef int i32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ u32x4 bf8x8_to_f16(i32x2 x) {
-  u32x4 r;
-  r[0] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_f16_bf8((unsigned)x[0], 1.0f, false));
-  r[1] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_f16_bf8((unsigned)x[0], 1.0f, true));
-  r[2] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_f16_bf8((unsigned)x[1], 1.0f, false));
-  r[3] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_f16_bf8((unsigned)x[1], 1.0f, true));
-  return r;
-}
-// w_out of feature f from the permuted copy in the prepared `small` section ([(h*NT + t)*16 + j], row = 32t + R(j) + 4h)
-__device__ __forceinline__ float wout_of(const float* wout_perm, int NT, int f) {
-  const int t = f >> 5, w = f & 31, h = (w >> 2) & 1, j = (w & 3) + 4 * (w >> 3);
-  return wout_perm[(h * NT + t) * 16 + j];
-}
-// ratio that restores f16(w_out) from its stashed bf8 image (0 when the image underflowed to 0)
-__device__ __forceinline__ float s8_wout_fix(float w) {
-  const _Float16 wh = (_Float16)w;
-  s16x2 v = {0, 0};
-  v = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(v, (f16x2_t){wh, wh}, 1.0f / (float)(1 << AFX_S8_JSHIFT), false);
-  const float dec = (float)__builtin_amdgcn_cvt_scalef32_pk_f16_bf8(__builtin_bit_cast(unsigned, v), 1.0f, false)[0];
-  return dec != 0.f ? (float)wh * (float)(1 << AFX_S8_JSHIFT) / dec : 0.f;
-}
-
+// Weight gradients from the 8-bit stash (f16 mode, S8): H_{l-1} and dZ'_l = g_hat J_l 2^JSHIFT as bf8 (e5m2), layout
+// [row>>5][p8>>4][row&31][16 B], contracted on the block-scaled matrix instruction
+//   v_mfma_scale_f32_32x32x64_f8f6f4 (bf8 x bf8, K = 64 = one stage of two 32-sample groups, twice the bf16 MFMA rate):
+//   dW_l 2^(JSHIFT - E) = sum_groups 2^(e_g - E) * sum_{n in group} dZ'_l[n][o] H_{l-1}[n][i]
+// K-blocks of the instruction (measured, tools/micro/mx_probe.hip and mx_probe2.hip): element (lane half, register, byte)
+// of A meets the same element of B; block 0 = registers 0-3 of BOTH lane halves, scaled by the E8M0 byte the lanes of
+// half 0 supply; block 1 = registers 4-7, scaled by the lanes of half 1.  So group 0 of the stage (32 samples) fills
+// registers 0-3 (16 samples per lane half), group 1 registers 4-7, the group's exponent e_g - E is the A operand's block
+// scale, and no per-sample factor is left for the VALU: the bf8 bytes go from LDS to the matrix pipe unconverted.
+// A 64-sample stage is 2 x F/16 LDS-DMA instructions (lane = stage row, 16 bytes); four ds_read_b64_tr_b8 deliver the
+// 32 samples x 1 position of a lane (lane 2q+p of a 16-lane group supplies row q, bytes 8p..8p+7 of a 16-byte chunk; lane
+// i receives byte i of the 8 rows).  Chunk columns are padded to 1152 B: the two 16-lane groups of a half-wave read 128
+// contiguous bytes each, 32 banks apart.  Bias gradients: one more MFMA per stage against a B operand of ones.
 // Pipeline: a ring of NS = 4 stages in LDS (the 8-bit stage is 36 KiB), NS-1 stages of LDS-DMA in flight per workgroup
 // (~100 KB per CU: enough to cover the HBM latency at full bandwidth; with one stage in flight the kernel ran at the
 // DMA round trip per stage, 2.6 TB/s).  One barrier per stage; every wave waits for its OWN DMA instructions of the
-// stage with a counted vmcnt (they complete in order), the barrier then covers the other waves' pieces.  dL/draw of the
-// stage's rows rides along as a 256-byte DMA by wave 0.
+// stage with a counted vmcnt (they complete in order), the barrier then covers the other waves' pieces.  The two group
+// exponents of the stage ride along as a 256-byte DMA by wave 0.
 // Every LDS read of the loop is inline asm: hipcc orders a plain LDS load (and the ds_read_tr builtins) behind ALL
 // outstanding LDS-DMA with an s_waitcnt vmcnt(0), which would put the whole DMA round trip back in front of every stage.
-// Bias gradients come out of the matrix pipe as well: the B fragment whose 8 elements are (g Ls) of the 8 rows is the
-// same for all 32 columns, so one extra MFMA per k-step and wave gives sum_n (g_n Ls) J[n][o] for a 32-row tile.
+// ---------------------------------------------------------------------------------------
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void lds_tr8(i32x2& dst, uint32_t addr, int imm) {
   asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm) : "memory");
 }
-__device__ __forceinline__ void lds_rd128f(f32x4& dst, uint32_t addr, int imm) {
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm) : "memory");
+__device__ __forceinline__ void lds_rd32(int& dst, uint32_t addr, int imm) {
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm) : "memory");
 }
 
 template <int F>
@@ -959,14 +954,14 @@ __global__ void __launch_bounds__(512) k_wgrad_s8(const WgradArgs a) {
   constexpr int CS = KB * 16 + 128;
   constexpr int IMG = NCH * CS;
   constexpr int NS = 4;                      // ring depth
-  constexpr int GOFF = NS * 2 * IMG;         // per stage: 64 x f32 dL/draw
+  constexpr int GOFF = NS * 2 * IMG;         // per stage: the two group exponents, replicated over 64 dwords
   constexpr int PER = 2 * ((NCH + 7) / 8);   // LDS-DMA instructions per wave and stage (waves beyond NCH: none, their waits are no-ops)
-  static_assert(2 * (NT - 1) * CS + 3 * 256 + 1151 < 65536 && IMG < 65536, "ds offset immediates are 16 bits");
+  static_assert(2 * (NT - 1) * CS + 3 * 128 + 1151 < 65536 && IMG < 65536, "ds offset immediates are 16 bits");
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, col = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int layer = blockIdx.y + 1, split = blockIdx.x;
-  const float ls = ldexpf(1.f, -wgrad_scale_exp(a.gmax));
+  const int E = wgrad_scale_exp(a.gmax);
   const char* A = (const char*)a.stash_dz + (size_t)layer * a.stride_rows * F;
   const char* B = (const char*)a.stash_h + (size_t)(layer - 1) * a.stride_rows * F;
   int64_t r0 = (int64_t)split * a.rows_per_split;
@@ -975,7 +970,6 @@ __global__ void __launch_bounds__(512) k_wgrad_s8(const WgradArgs a) {
   const int nst = r1 > r0 ? (int)((r1 - r0) / KB) : 0;
   const bool active = wave < WR * WC;
   const int wr = wave / WC, wc = wave % WC;
-  const bool lastl = layer == a.n_hidden;
   const bool has_bias = active && wc < TR;   // this wave also sums the bias gradient of its row tile wc
 
   f32x16 acc[TR][TC], accb = (f32x16){0.f};
@@ -983,13 +977,7 @@ __global__ void __launch_bounds__(512) k_wgrad_s8(const WgradArgs a) {
   for (int i = 0; i < TR; ++i)
 #pragma unroll
     for (int j = 0; j < TC; ++j) acc[i][j] = (f32x16){0.f};
-  // layer N: per-lane correction of the A rows this wave owns (lane&31 = row of the 32-position tile)
-  f16x8_t afix[TR];
-#pragma unroll
-  for (int i = 0; i < TR; ++i) {
-    const _Float16 r = (_Float16)(lastl ? s8_wout_fix(wout_of(a.wout_perm, NT, fperm8(32 * (wr * TR + i) + col))) : 1.f);
-    afix[i] = (f16x8_t){r, r, r, r, r, r, r, r};
-  }
+  const i32x8 ones8 = {0x3c3c3c3c, 0x3c3c3c3c, 0x3c3c3c3c, 0x3c3c3c3c, 0x3c3c3c3c, 0x3c3c3c3c, 0x3c3c3c3c, 0x3c3c3c3c};     // bf8 1.0
 
   auto stage_load = [&](int st) {
     const int buf = st % NS;
@@ -1001,12 +989,13 @@ __global__ void __launch_bounds__(512) k_wgrad_s8(const WgradArgs a) {
       __builtin_amdgcn_global_load_lds(GPTR(A + src), LPTR(dA + c * CS), 16, 0, 0);
       __builtin_amdgcn_global_load_lds(GPTR(B + src), LPTR(dB + c * CS), 16, 0, 0);
     }
-    if (wave == 0) __builtin_amdgcn_global_load_lds(GPTR(a.graw + r0 + (int64_t)st * KB + lane), LPTR(lds + GOFF + buf * (KB * 4)), 4, 0, 0);
+    if (wave == 0) __builtin_amdgcn_global_load_lds(GPTR(a.gexp + g0 + hh), LPTR(lds + GOFF + buf * (KB * 4)), 4, 0, 0);
   };
   const int g4 = lane >> 4, li = lane & 15;
-  // lane 2q+p of a 16-lane group: row q of the 8-row block, bytes 8p..8p+7 of chunk 2T + (g4&1)
+  // lane 2q+p of a 16-lane group: row q of an 8-row block, bytes 8p..8p+7 of chunk 2T + (g4&1); read r (registers 2r, 2r+1)
+  // of lane half h covers stage rows 32 (r>>1) + 16 h + 8 (r&1) + 0..7
   const uint32_t lbase = (uint32_t)(uintptr_t)LPTR(lds);
-  const uint32_t troff = (uint32_t)((g4 & 1) * CS + (8 * (g4 >> 1) + (li >> 1)) * 16 + 8 * (li & 1));
+  const uint32_t troff = (uint32_t)((g4 & 1) * CS + (16 * (g4 >> 1) + (li >> 1)) * 16 + 8 * (li & 1));
   const uint32_t offA = troff + (uint32_t)(2 * wr * TR * CS), offB = troff + (uint32_t)(IMG + 2 * wc * TC * CS);
 
 #pragma unroll
@@ -1028,42 +1017,31 @@ __global__ void __launch_bounds__(512) k_wgrad_s8(const WgradArgs a) {
     if (st + NS - 1 < nst) stage_load(st + NS - 1);
     if (active) {
       const uint32_t sbase = lbase + (uint32_t)((st % NS) * 2 * IMG);
-      const uint32_t gbase = lbase + (uint32_t)(GOFF + (st % NS) * (KB * 4) + 32 * hh);
-      // the reads of k-step ks+1 are issued before the MFMAs of k-step ks (two register sets)
-      i32x2 ax[2][TR], bx[2][TC];
-      f32x4 ga[2], gb[2];
-      auto issue = [&](int ks, int b) {
+      i32x2 ax[TR][4], bx[TC][4];
+      int eg;
 #pragma unroll
-        for (int i = 0; i < TR; ++i) lds_tr8(ax[b][i], sbase + offA, 2 * i * CS + ks * 256);
+      for (int i = 0; i < TR; ++i)
 #pragma unroll
-        for (int j = 0; j < TC; ++j) lds_tr8(bx[b][j], sbase + offB, 2 * j * CS + ks * 256);
-        lds_rd128f(ga[b], gbase, ks * 64);
-        lds_rd128f(gb[b], gbase, ks * 64 + 16);
-      };
-      issue(0, 0);
+        for (int q = 0; q < 4; ++q) lds_tr8(ax[i][q], sbase + offA, 2 * i * CS + (q >> 1) * 512 + (q & 1) * 128);
 #pragma unroll
-      for (int ks = 0; ks < KB / 16; ++ks) {
-        const int b = ks & 1;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        // element j of a fragment is stage row 16 ks + 8 hh + j: eight (g Ls), packed to f16 pairs (same for the half-wave)
-        const u32x4 gpk = {pack2h(ga[b][0] * ls, ga[b][1] * ls), pack2h(ga[b][2] * ls, ga[b][3] * ls),
-                           pack2h(gb[b][0] * ls, gb[b][1] * ls), pack2h(gb[b][2] * ls, gb[b][3] * ls)};
-        const f16x8_t gp = __builtin_bit_cast(f16x8_t, gpk);
-        u32x4 af[TR], bf[TC];
+      for (int j = 0; j < TC; ++j)
 #pragma unroll
-        for (int i = 0; i < TR; ++i) {
-          af[i] = bf8x8_to_f16(ax[b][i]);
-          if (lastl) af[i] = __builtin_bit_cast(u32x4, __builtin_bit_cast(f16x8_t, af[i]) * afix[i]);
-        }
+        for (int q = 0; q < 4; ++q) lds_tr8(bx[j][q], sbase + offB, 2 * j * CS + (q >> 1) * 512 + (q & 1) * 128);
+      lds_rd32(eg, lbase + (uint32_t)(GOFF + (st % NS) * (KB * 4)) + (uint32_t)lane * 4u, 0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // E8M0 block scale supplied by this lane half for ITS group (half 0 -> block 0 = group 0): 2^(e_group - E) (e_group <= E; a group without gradient has e_group = 0 and zeros)
+      int sc = 127 + eg - E;
+      sc = sc < 0 ? 0 : (sc > 127 ? 127 : sc);
+      i32x8 b8[TC];
 #pragma unroll
-        for (int j = 0; j < TC; ++j) bf[j] = __builtin_bit_cast(u32x4, __builtin_bit_cast(f16x8_t, bf8x8_to_f16(bx[b][j])) * gp);
-        if (ks + 1 < KB / 16) issue(ks + 1, b ^ 1);
+      for (int j = 0; j < TC; ++j) b8[j] = (i32x8){bx[j][0][0], bx[j][0][1], bx[j][1][0], bx[j][1][1], bx[j][2][0], bx[j][2][1], bx[j][3][0], bx[j][3][1]};
 #pragma unroll
-        for (int i = 0; i < TR; ++i) {
+      for (int i = 0; i < TR; ++i) {
+        const i32x8 a8 = {ax[i][0][0], ax[i][0][1], ax[i][1][0], ax[i][1][1], ax[i][2][0], ax[i][2][1], ax[i][3][0], ax[i][3][1]};
 #pragma unroll
-          for (int j = 0; j < TC; ++j) acc[i][j] = mfma_f16(af[i], bf[j], acc[i][j]);
-          if (i == wc) accb = mfma_f16(af[i], gpk, accb);          // (wc < TR: wave-uniform)
-        }
+        for (int j = 0; j < TC; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8[j], acc[i][j], 1, 1, 0, sc, 0, 127);
+        if (i == wc) accb = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, ones8, accb, 1, 1, 0, sc, 0, 127);      // (wc < TR: wave-uniform)
       }
     }
   }

@@ -15,7 +15,7 @@ def make_model(layers, width, precision):
     return CPPN(md).to(DEV)
 def grads(m): return {k: p.grad.detach().cpu().numpy().copy() for k, p in m.named_parameters() if p.grad is not None}
 L, W = int(os.environ.get("L", 2)), int(os.environ.get("W", 64))
-for prec in ["f16", "bf16"]:
+for prec in os.environ.get("PRECS", "f16,bf16").split(","):
     torch.manual_seed(3)
     m = make_model(L, W, prec)
     with torch.no_grad():
