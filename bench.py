@@ -105,7 +105,7 @@ def main():
     from nerf_for_angiography_amd import dist as afx_dist
     from nerf_for_angiography_amd.model.CPPN import CPPN
     from nerf_for_angiography_amd.render import render_projection, render_rays, train_step_mse, projection_spec
-    from nerf_for_angiography_amd.phantomdata.helpers import capsule_tree, capsule_mu, ray_tracing_fn as ray_tracing, get_ray_values
+    from nerf_for_angiography_amd.phantomdata.helpers import capsule_tree, capsule_mu, get_ray_values
 
     rank, world, device = afx_dist.init_from_env()
     if not torch.cuda.is_available():
@@ -133,19 +133,32 @@ def main():
     sync.on_call = (t_allreduce.begin, t_allreduce.end)
     opt = torch.optim.Adam(list(model.parameters()), lr=1e-4)
 
-    # synthetic P-ANGIO phantom: 31-capsule vessel tree, mu = 0.2, targets by the GT projector
+    # synthetic P-ANGIO phantom: 31-capsule vessel tree, mu = 0.2, voxelised once on a 192^3 grid over +-100 and
+    # projected by the HIP ground-truth projector (afx_project_volume: all projections of this rank in ONE launch, rays
+    # generated in the kernel from the poses) - set-up, outside the timed region
+    from nerf_for_angiography_amd.phantomdata.helpers import VoxelVolume
+    from nerf_for_angiography_amd.engine import project_volume
     caps = capsule_tree(levels=5, seed=0)
     n_proj = args.steps + args.warmup
-    poses, targets = [], []
-    z_gt = torch.linspace(0., 1., 160, device=device) * (far - near) + near
+    ax = np.linspace(-100.0, 100.0, 192)
+    with torch.no_grad():
+        tx = torch.from_numpy(ax).float().to(device)
+        gx, gy, gz = torch.meshgrid(tx, tx, tx, indexing="ij")
+        mu = torch.cat([capsule_mu(torch.stack([gx[i0:i0 + 16], gy[i0:i0 + 16], gz[i0:i0 + 16]], -1).reshape(-1, 3), caps)
+                        for i0 in range(0, 192, 16)]).reshape(192, 192, 192)
+        del gx, gy, gz
+    vol = VoxelVolume(ax, ax, ax, mu.cpu().numpy(), fill_value=0.0, device=device)
+    poses = []
     for i in range(n_proj):
         theta = 2.0 * (i * world + rank)
-        o, d, m44, _, _ = get_ray_values(theta, 0.0, 0.0, np.array([0, 0, 1500.0]), W, H, focal, device)
+        _, _, m44, _, _ = get_ray_values(theta, 0.0, 0.0, np.array([0, 0, 1500.0]), 2, 2, focal, "cpu")
         poses.append(torch.from_numpy(m44[None]).to(device))
-        with torch.no_grad():
-            targets.append(ray_tracing(lambda p: capsule_mu(p, caps), o.reshape(-1, 3).float(), d.reshape(-1, 3).float(),
-                                       z_gt, batch_rays=16384).reshape(-1).contiguous())
-    del o, d
+    z_gt = torch.linspace(0., 1., 160, device=device) * (far - near) + near
+    with torch.no_grad():
+        tg = project_volume(vol.values, vol.origin, vol.spacing, vol.fill_value, z_gt, poses=torch.cat(poses), width=W, height=H,
+                            focal=focal, type_ct=True)
+    targets = [t.contiguous() for t in tg.view(n_proj, W * H)]
+    del tg, mu
 
     fused = not args.unfused and args.precision != "f32"
     n_global = world * W * H          # the loss is the mean over the GLOBAL batch; the all-reduce is a SUM (dist.GradSync)

@@ -214,10 +214,30 @@ class CPPN(nn.Module):
             return self.fourier_coefficients.detach().to(dev, torch.float32).contiguous()
         return None
 
+    def invalidate(self):
+        """Drop the cached re-tiled weights.  Needed after writes the version counters cannot see: `p.data.copy_(...)`,
+        `p.data.normal_()`, initialisers applied through `.data`, EMA code.  (Optimizer steps, `load_state_dict`, in-place
+        ops on the parameters and writes to `flat_params` are tracked automatically.)"""
+        if self._engine is not None:
+            self._engine._prepared.clear()
+
+    def _check_views(self):
+        """Every Linear's weight / bias must still alias the flat buffer the kernels read: rebinding `p.data = ...`
+        (e.g. torch.nn.utils.vector_to_parameters) detaches it.  Cheap pointer comparison; re-flatten when broken."""
+        layout, _ = self._layout()
+        base, esz = self._flat.data_ptr(), self._flat.element_size()
+        for lin, (wo, bo, rows, cols) in zip(self._linears(), layout):
+            if lin.weight.data_ptr() != base + wo * esz or lin.bias.data_ptr() != base + bo * esz:
+                self._flatten()
+                self.invalidate()
+                return
+
     def _prepared(self):
-        """Prepared (re-tiled) weights for the current parameter values.  Cached on the version counters
-        of the parameters (bumped by every in-place optimizer update / load_state_dict) and of the flat
-        buffer itself (bumped by direct writes such as a broadcast)."""
+        """Prepared (re-tiled) weights for the current parameter values.  Cached on the version counters of the
+        parameters (bumped by every in-place optimizer update / load_state_dict) and of the flat buffer itself (bumped by
+        direct writes such as a broadcast); parameters that no longer alias the flat buffer are re-flattened first.
+        Writes through `.data` bump no counter: call `invalidate()` after them."""
+        self._check_views()
         aux_key = None
         if self.use_pos_enc == "barf":
             aux_key = float(self.barf_alpha)

@@ -746,6 +746,47 @@ def test_training_driver_reference_loop_with_grid(tmp_path):
     assert 0 < h[-1]["marched_samples_per_iter"] < 256 * 100
 
 
+def test_training_precision_tracks_fp32_convergence():
+    """before a reduced precision is the training default, show it converges like fp32.  The same model, rays,
+    targets and Adam settings are trained 150 iterations at f32 (render + autograd), f16 and f16s8 (fused train step): the
+    loss curves agree to a fraction of a percent and the final PSNRs to 0.05 dB."""
+    from nerf_for_angiography_amd.render import render_projection, train_step_mse, projection_spec
+    from nerf_for_angiography_amd.phantomdata.helpers import get_ray_values, capsule_tree, capsule_mu, ray_tracing_fn
+    W, S, near, far = 64, 64, 1400.0, 1600.0
+    caps = capsule_tree(levels=4, seed=1)
+    poses, targets = [], []
+    z_gt = torch.linspace(near, far, 128, device=DEV)
+    for th in (0.0, 45.0, 90.0, 135.0):
+        o, d, m44, _, _ = get_ray_values(th, 0.0, 0.0, np.array([0, 0, 1500.0]), W, W, 13.0 * W, DEV)
+        poses.append(torch.from_numpy(m44[None]).to(DEV))
+        targets.append(ray_tracing_fn(lambda p: capsule_mu(p, caps), o.reshape(-1, 3).float(), d.reshape(-1, 3).float(), z_gt).reshape(-1))
+    curves = {}
+    for prec in ("f32", "f16", "f16s8"):
+        torch.manual_seed(21)
+        m = make_model(4, 128, precision=prec)
+        with torch.no_grad():
+            m.output_linear[0].bias.fill_(-5.0)
+        opt = torch.optim.Adam(list(m.parameters()), lr=5e-4)
+        losses = []
+        for it in range(150):
+            i = it % 4
+            opt.zero_grad()
+            if prec == "f32":
+                loss = torch.nn.functional.mse_loss(render_projection(m, poses[i], W, W, 13.0 * W, S, near, far).rgb_map, targets[i])
+                loss.backward()
+            else:
+                loss, _ = train_step_mse(m, projection_spec(poses[i], W, W, 13.0 * W, S, near, far), targets[i])
+            opt.step()
+            losses.append(float(loss))
+        curves[prec] = np.array(losses)
+    assert curves["f32"][-8:].mean() < 0.5 * curves["f32"][:8].mean()            # it does train
+    for prec in ("f16", "f16s8"):
+        tail = slice(-20, None)
+        rel = abs(curves[prec][tail].mean() - curves["f32"][tail].mean()) / curves["f32"][tail].mean()
+        dpsnr = abs(10 * np.log10(curves[prec][tail].mean() / curves["f32"][tail].mean()))
+        assert rel < 2e-2 and dpsnr < 0.1, (prec, rel, dpsnr)
+
+
 def test_training_driver_runs_and_checkpoints(tmp_path):
     """Mirror of nerf/run_nerf_acc.py on a tiny synthetic dataset: loss goes down, the best checkpoint has the
     reference's dictionary layout and reloads into a fresh CPPN; 300 samples/ray (the reference's setting,

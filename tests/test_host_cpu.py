@@ -169,6 +169,22 @@ def test_cppn_parameters_are_views_of_one_flat_buffer(tmp_path):
 
 
 # ---------------------------------------------------------------- helper mirrors on the host
+def test_cppn_rebinding_data_is_detected():
+    """`p.data = ...` detaches a parameter from the flat buffer the kernels read; the model re-flattens."""
+    from nerf_for_angiography_amd.model.CPPN import CPPN
+    torch.manual_seed(0)
+    m = CPPN(model_def(4, 64))
+    lin = m._linears()[1]
+    new_w = torch.randn_like(lin.weight)
+    lin.weight.data = new_w.clone()                      # what torch.nn.utils.vector_to_parameters does
+    assert lin.weight.data_ptr() != m.flat_params.data_ptr() + m._layout()[0][1][0] * 4
+    m._check_views()
+    wo = m._layout()[0][1][0]
+    assert lin.weight.data_ptr() == m.flat_params.data_ptr() + wo * 4
+    assert torch.equal(m.flat_params[wo:wo + 64 * 64].view(64, 64), new_w)
+    m.invalidate()                                        # no engine yet: a no-op, must not raise
+
+
 def test_pose_and_ray_helpers_match_golden(golden):
     from nerf_for_angiography_amd.phantomdata import proj_helpers as ph
     from nerf_for_angiography_amd.phantomdata.helpers import get_ray_values, get_depth_values
