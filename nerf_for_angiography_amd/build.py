@@ -13,7 +13,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 DEPS = ["afx_api.hip", "afx_kernels_f32.hip", "afx_kernels_bf16.hip", "afx_inst.h", "afx_inst_chain16.hip",
         "afx_internal.h", os.path.join("..", "..", "include", "afx.h")]
-VARIANTS = {"": [], "safe": ["-DAFX_SAFE_WAITS"]}
+VARIANTS = {"": [], "safe": ["-DAFX_SAFE_WAITS"],
+            "stamp": ["-DAFX_STAMP", "-DAFX_SINGLE_TU"]}      # diagnostic: per-phase cycle stamps of the backward chain kernel (one translation unit)
 
 
 def lib_path(variant: str = "") -> str:
@@ -63,8 +64,9 @@ def build(force: bool = False, verbose: bool = False, variant: str = "", jobs: i
         return obj
 
     jobs = jobs or min(8, os.cpu_count() or 1)
+    units = [u for u in _units() if u[0] == "api"] if "-DAFX_SINGLE_TU" in VARIANTS[variant] else _units()
     with ThreadPoolExecutor(max_workers=jobs) as ex:
-        objs = list(ex.map(compile_one, _units()))
+        objs = list(ex.map(compile_one, units))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
     if verbose:
         print(" ".join(cmd), flush=True)

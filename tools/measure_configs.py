@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of the BASELINE.json configurations on one MI355X (fills BASELINE.md section 3).
 C2: 256^2 x 64, 8x256; C3: 512^2 x 128 coarse + 64 fine (hierarchical, dense convention), 8x256;
-C4 (1 GPU): 512^2 x 128; C5 (1 GPU): 1024^2 x 256.  fwd+bwd+Adam, bf16, one projection per step."""
+C4 (1 GPU): 512^2 x 128; C5 (1 GPU): 1024^2 x 256.  fwd+bwd+Adam, f16s8 (the training precision), one projection per step."""
 import json, os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, torch
@@ -11,7 +11,7 @@ from nerf_for_angiography_amd.nerf.nerf_helpers import fine_sampling
 from nerf_for_angiography_amd.phantomdata.helpers import get_ray_values
 
 dev = torch.device("cuda:0")
-def model(prec="bf16"):
+def model(prec="f16s8"):
     torch.manual_seed(0)
     md = dict(num_early_layers=8, num_late_layers=0, num_filters=256, num_input_channels=3, num_output_channels=1,
               num_input_channels_views=0, use_bias=True, pos_enc="none", pos_enc_basis=5, act_func="relu", fourier_sigma=5,
@@ -55,31 +55,41 @@ t = timeit(step3)
 out["C3 512^2x(128 coarse + 192 fine)"] = dict(ms_per_step=round(t * 1e3, 2), ray_samples_per_s=round(W * W * (SC + SC + NF) / t / 1e6, 1))
 print("C3", out["C3 512^2x(128 coarse + 192 fine)"], flush=True)
 # forward-only renders (evaluation): split-bf16 and bf16
-for prec in ("bf16x3", "bf16"):
+for prec in ("bf16x3", "f16"):
     m = model(prec)
     pose = torch.from_numpy(get_ray_values(20.0, 0.0, 0.0, np.array([0, 0, 1500.0]), 512, 512, 13.0 * 512, dev)[2][None]).to(dev)
     with torch.no_grad():
         t = timeit(lambda: render_projection(m, pose, 512, 512, 13.0 * 512, 128, 1400.0, 1600.0))
     out[f"forward 512^2x128 {prec}"] = dict(ms=round(t * 1e3, 2), ray_samples_per_s=round(512 * 512 * 128 / t / 1e6, 1))
     print(prec, out[f"forward 512^2x128 {prec}"], flush=True)
-# the reference's own training iteration (run_nerf_acc.py:142-155): 75^2 = 5 625 rays x 300 samples, 4x128 MLP (and 8x256),
-# ray arrays as sample_pixel_rays returns them; fused train step + Adam per iteration
-from nerf_for_angiography_amd.engine import RenderSpec
+# the reference's own training iteration (run_nerf_acc.py:142-155,263-307): 75^2 = 5 625 rays x 300 samples, 4x128 MLP (and 8x256),
+# END TO END: the batch is drawn on the device from a resident table of 90 projections x 100 x 100 rays (weighted sampling
+# without replacement, engine.sample_rays) - no pandas, no host round trip - then the train step + Adam
+from nerf_for_angiography_amd.engine import RenderSpec, sample_rays
+NT = 90 * 100 * 100
+tab_o = torch.randn(NT, 3, device=dev) * 3 + torch.tensor([0, 0, 1500.0], device=dev)
+tab_d = torch.nn.functional.normalize(torch.randn(NT, 3, device=dev) * 0.03 + torch.tensor([0, 0, -1.0], device=dev), dim=-1)
+tab_p, tab_w = torch.rand(NT, device=dev), torch.rand(NT, device=dev) + 0.05
 for layers, width in ((4, 128), (8, 256)):
     torch.manual_seed(0)
     md = dict(num_early_layers=layers, num_late_layers=0, num_filters=width, num_input_channels=3, num_output_channels=1,
               num_input_channels_views=0, use_bias=True, pos_enc="none", pos_enc_basis=5, act_func="relu", fourier_sigma=5,
-              num_img=1, device=dev, precision="bf16")
+              num_img=1, device=dev, precision="f16s8")
     m = CPPN(md).to(dev); opt = torch.optim.Adam(m.parameters(), lr=1e-4)
     R, S = 5625, 300
-    o = torch.randn(R, 3, device=dev) * 3 + torch.tensor([0, 0, 1500.0], device=dev)
-    d = torch.nn.functional.normalize(torch.randn(R, 3, device=dev) * 0.03 + torch.tensor([0, 0, -1.0], device=dev), dim=-1)
-    tgt = torch.rand(R, device=dev)
-    spec = RenderSpec(n_rays=R, n_samples=S, origins=o, dirs=d, mode="acc", t_near=1400.0, t_far=1600.0)
+    step_no = [0]
     def it():
+        step_no[0] += 1
+        o, d, tgt, _ = sample_rays(tab_o, tab_d, tab_p, tab_w, R, seed=0, stream_id=step_no[0])
+        spec = RenderSpec(n_rays=R, n_samples=S, origins=o, dirs=d, mode="acc", t_near=1400.0, t_far=1600.0)
         opt.zero_grad(set_to_none=True); train_step_mse(m, spec, tgt); opt.step()
     t = timeit(it, warm=5, steps=50)
+    def sample_only():
+        step_no[0] += 1
+        sample_rays(tab_o, tab_d, tab_p, tab_w, R, seed=0, stream_id=step_no[0])
+    ts = timeit(sample_only, warm=2, steps=50)
     out[f"reference training iteration 5625x300 {layers}x{width}"] = dict(ms_per_iter=round(t * 1e3, 3), iters_per_s=round(1 / t, 1),
-                                                                          ray_samples_per_s=round(R * S / t / 1e6, 1))
+                                                                          ray_samples_per_s=round(R * S / t / 1e6, 1),
+                                                                          device_sampler_ms=round(ts * 1e3, 3))
     print(f"train-iter {layers}x{width}", out[f"reference training iteration 5625x300 {layers}x{width}"], flush=True)
 json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out", "configs.json"), "w"), indent=1)
