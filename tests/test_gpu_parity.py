@@ -1113,7 +1113,7 @@ def test_stratified_depths_fused():
 
 @pytest.mark.parametrize("layers,width,n_samples,n_rays", [(1, 64, 2, 1), (2, 128, 33, 7), (12, 64, 32, 40), (3, 256, 5, 3),
                                                               (5, 128, 96, 257)])
-@pytest.mark.parametrize("prec", ["f32", "bf16"])
+@pytest.mark.parametrize("prec", ["f32", "bf16", "f16", "f16s8"])
 def test_odd_shapes_vs_oracle(layers, width, n_samples, n_rays, prec):
     """Edge geometry: a single ray, 2 samples, sample counts that are not multiples of 32, 1 and 12 hidden layers, ray
     counts that leave most of the last workgroup tile empty."""
@@ -1133,13 +1133,19 @@ def test_odd_shapes_vs_oracle(layers, width, n_samples, n_rays, prec):
     out = render_rays(m, o.to(DEV), d.to(DEV), n_samples, 1450.0, 1550.0, mode="acc")
     torch.nn.functional.mse_loss(out.rgb_map, tgt.to(DEV)).backward()
     assert out.rgb_map.shape == (n_rays,)
-    # few, thick steps (dt up to 50) give plain bf16 no averaging over samples: its error bar is 4x wider here
-    loose = 4 if prec == "bf16" else 1
-    assert rel_l2(out.rgb_map.detach().cpu().numpy(), pix_c.numpy()) < loose * TOL[prec]["pix"]
+    # few, thick steps (dt up to 50) give the 16-bit modes no averaging over samples: their error bars are 4x wider here;
+    # the bf8 stash rounds each operand of the weight-gradient sum to 2 significant bits (12 % per term, zero-mean):
+    # with 2 ... 25 000 terms per sum instead of millions its bar is 0.25 - this case checks geometry, not precision
+    loose = 1 if prec == "f32" else 4
+    # (thick steps: optical depths of tens, so a pixel's RELATIVE error is its optical depth's ABSOLUTE error: the f16 modes'
+    # 1e-4 of an optical depth of 40 is 4e-3 on the pixel; their bar for well-conditioned renders is asserted elsewhere)
+    ptol = 1e-2 if prec in ("f16", "f16s8") else loose * TOL[prec]["pix"]
+    assert rel_l2(out.rgb_map.detach().cpu().numpy(), pix_c.numpy()) < ptol
     got = _grads_by_name(m)
+    gtol = 0.25 if prec == "f16s8" else 2 * loose * TOL[prec]["grad"]
     for k, v in grads_c.items():
         if float(v.abs().max()) > 0:
-            assert rel_l2(got[k], v.numpy()) < 2 * loose * TOL[prec]["grad"], k
+            assert rel_l2(got[k], v.numpy()) < gtol, k
 
 
 def test_model_too_deep_for_lds_is_refused():
