@@ -270,6 +270,13 @@ int afx_gather_rays(const float* origins, const float* dirs, const float* pixels
 /* out[i] = uniform [0,1) number i of Philox4x32-10 stream (seed, stream_id): the generator of every "perf mode" draw */
 int afx_philox_uniform(uint64_t seed, uint64_t stream_id, int64_t n, float* out, void* stream);
 
+/* Trainable fourier coefficients (model/CPPN.py:92 makes them an nn.Parameter; fourier_pos_enc, CPPN.py:320-327, is
+ * differentiable in them).  After this call every backward entry point (afx_mlp_backward, afx_render_backward,
+ * afx_train_step_mse) at a 16-bit precision also does d_enc_aux[3*n_freq] += d loss / d coefficients; `params` is the
+ * fp32 flat parameter vector the prepared buffer was made from (W_0 is read from it).  d_enc_aux = NULL switches it
+ * off (the default: the coefficients are constants).  AFX_PREC_F32 backward calls fail while it is on. */
+int afx_set_encoding_grad(afx_ctx* ctx, const float* params, float* d_enc_aux);
+
 /* Measurement aid (bench.py's roofline leg): when enabled, every launch of the three MFMA kernels is
  * bracketed by HIP events recorded on the launch stream.  afx_profile_read blocks on those events
  * (the only call in this library that synchronises), returns the summed device time and the launch

@@ -68,6 +68,7 @@ _SIGS = {
     "afx_project_volume": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                      C.c_float, C.POINTER(RenderArgs), C.c_int, C.c_void_p]),
     "afx_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "afx_set_encoding_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "afx_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "afx_fine_depths": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                   C.c_void_p, C.c_void_p]),

@@ -56,6 +56,8 @@ struct afx_ctx {
   int overlap, persistent_chain;
   int small_in_kernel;   // first-/output-layer gradient sums inside the backward chain kernel (AFX_SMALL_IN_KERNEL=0: off)
   int device;            // the HIP device this context was created on; every entry point checks it is current
+  const float* coef_params = nullptr;   // afx_set_encoding_grad: fp32 flat parameters (W_0 is read from them) ...
+  float* d_coef = nullptr;              // ... and where d loss / d fourier coefficients accumulates (null: coefficients are constants)
   std::vector<ProfRec> recs;
 };
 
@@ -181,6 +183,16 @@ extern "C" void afx_destroy(afx_ctx* c) {
   for (auto e : c->ev_wgrad) if (e) (void)hipEventDestroy(e);
   if (c->side) (void)hipStreamDestroy(c->side);
   delete c;
+}
+
+extern "C" int afx_set_encoding_grad(afx_ctx* c, const float* params, float* d_enc_aux) {
+  if (!c) return fail(AFX_E_INVALID, "afx_set_encoding_grad: null ctx");
+  if (d_enc_aux && c->d.enc != AFX_ENC_FOURIER)
+    return fail(AFX_E_INVALID, "afx_set_encoding_grad: only the fourier encoding has trainable coefficients");
+  if (d_enc_aux && !params) return fail(AFX_E_INVALID, "afx_set_encoding_grad: params required");
+  c->coef_params = d_enc_aux ? params : nullptr;
+  c->d_coef = d_enc_aux;
+  return AFX_OK;
 }
 
 extern "C" int afx_profile_enable(afx_ctx* c, int on) {
@@ -492,6 +504,15 @@ static int launch_wgrad16_t(afx_ctx* c, const WgradArgs& w, const ReduceArgs& rd
   hipLaunchKernelGGL(k_reduce_w<F>, dim3((F * F + 255) / 256, N + 1), dim3(256), 0, st, rd);
   hipLaunchKernelGGL(k_reduce_b<F>, dim3(1, N + 2), dim3(F), 0, st, rd);
   hipLaunchKernelGGL(k_reduce_small<F>, dim3((unsigned)((F * rd.k0pad + 2 * F + 1 + 63) / 64)), dim3(64, 4), 0, st, rd);
+  if (c->d_coef && c->d.enc == AFX_ENC_FOURIER) {
+    // second pass over dZ_0 and the encoded inputs, against d(enc)/d(coef); the records of the first pass are reduced by now
+    WgradArgs w2 = w;
+    ReduceArgs r2 = rd;
+    w2.coef_cols = r2.coef_cols = 3 * c->d.n_freq;
+    r2.w0 = c->coef_params; r2.d_coef = c->d_coef;
+    hipLaunchKernelGGL((k_small_grads_bf16<F, true, H16>), dim3(rd.n_small, F / 64 * 4), dim3(256), 0, st, w2);
+    hipLaunchKernelGGL(k_reduce_coef<F>, dim3(r2.coef_cols), dim3(F), 0, st, r2);
+  }
   HIPCHK(hipGetLastError());
   return AFX_OK;
 }
@@ -525,6 +546,8 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
   const size_t fixed = head + B.fixed_bytes;
   const int TILE = bwd_tile(prec);
   const bool b16 = is_bf16(prec);
+  if (c->d_coef && c->d.enc == AFX_ENC_FOURIER && !b16)
+    return fail(AFX_E_INVALID, "backward: the fourier coefficients' gradient (afx_set_encoding_grad) needs a 16-bit precision");
   // in-kernel small gradients: 8-wave 16-bit backward kernel, rays, raw coordinates as inputs (AFX_SMALL_IN_KERNEL=0: off)
   const bool sg = b16 && a.mode == 1 && c->d.enc == AFX_ENC_NONE && c->small_in_kernel;
   const bool s8 = prec == AFX_PREC_F16S8 && sg;          // 8-bit stash: that configuration only; otherwise the 16-bit f16 path
@@ -603,12 +626,12 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
     rps = (rps + 63) / 64 * 64;        // whole 32-/64-sample stages
     w.rows_per_split = (int)rps;
     w.partial = partial; w.partial2 = partial2; w.partial_s = partial_s; w.debug = a.debug; w.small_groups = sg ? 1 : 0;
-    w.gmax = a.gmax; w.stash_esz = (int)esz; w.gexp = a.gexp;
+    w.gmax = a.gmax; w.stash_esz = (int)esz; w.gexp = a.gexp; w.coef_cols = 0;
     ReduceArgs rd;
     rd.partial = partial; rd.partial2 = partial2; rd.n_hidden = N; rd.k0 = c->k0; rd.k0pad = k0ld; rd.n_splits = splits;
     rd.grad = grad_flat; rd.hidden_only = b16 ? 1 : 0; rd.partial_s = partial_s;
     rd.n_small = kSmallBlocks;      // records; every record is written (possibly with zero rows)
-    rd.gmax = a.gmax; rd.scale_shift = s8 ? AFX_S8_JSHIFT : 0;
+    rd.gmax = a.gmax; rd.scale_shift = s8 ? AFX_S8_JSHIFT : 0; rd.w0 = nullptr; rd.d_coef = nullptr; rd.coef_cols = 0;
     if (!b16) rc = F == 64 ? launch_wgrad_t<64>(c, w, rd, N, ws_st) : (F == 128 ? launch_wgrad_t<128>(c, w, rd, N, ws_st) : launch_wgrad_t<256>(c, w, rd, N, ws_st));
     else if (s8) rc = F == 64 ? launch_wgrad8_t<64>(c, w, rd, N, ws_st) : (F == 128 ? launch_wgrad8_t<128>(c, w, rd, N, ws_st) : launch_wgrad8_t<256>(c, w, rd, N, ws_st));
     else if (h16) rc = F == 64 ? launch_wgrad16_t<64, true>(c, w, rd, N, ws_st) : (F == 128 ? launch_wgrad16_t<128, true>(c, w, rd, N, ws_st) : launch_wgrad16_t<256, true>(c, w, rd, N, ws_st));

@@ -96,6 +96,7 @@ struct WgradArgs {
   const uint32_t* gmax;     // f16 mode: the chunk's max |dL/draw| (scale of the contraction, wgrad_scale_exp)
   int32_t stash_esz;        // bytes per stash element (4 f32, 2 bf16/f16, 1 bf8)
   const int32_t* gexp;      // 8-bit stash: group exponents (block scales of the MX contraction)
+  int32_t coef_cols;        // k_small_grads_bf16, fourier encoding: > 0 = contract dZ_0 with d(enc)/d(coef) columns instead of enc (3*n_freq)
 };
 
 struct ReduceArgs {
@@ -108,6 +109,9 @@ struct ReduceArgs {
   float* grad;              // flat parameter gradient, accumulated into
   const uint32_t* gmax;     // f16 mode: hidden-layer partials carry the factor 2^-e (wgrad_scale_exp); null otherwise
   int32_t scale_shift;      // 8-bit stash: and the factor 2^scale_shift of the stashed J
+  const float* w0;          // k_reduce_coef: the first layer's fp32 weights [F, k0]
+  float* d_coef;            // k_reduce_coef: d loss / d fourier coefficients [coef_cols], accumulated into
+  int32_t coef_cols;
 };
 
 }  // namespace afx

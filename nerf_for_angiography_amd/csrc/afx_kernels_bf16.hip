@@ -1103,6 +1103,18 @@ __global__ void __launch_bounds__(256) k_small_grads_bf16(const WgradArgs a) {
     float ev[KMAX];
 #pragma unroll
     for (int c = 0; c < KMAX; ++c) ev[c] = c < a.k0 ? e[c] : 0.f;
+    if (ENC && a.coef_cols > 0) {
+      // fourier_pos_enc (model/CPPN.py:320-327): enc = [x | sin(2 pi x_c coef_m) | cos(2 pi x_c coef_m)], c = m % 3, so
+      // d enc[3+m]/d coef_m = 2 pi x_c cos(.) = 2 pi enc[c] enc[3+nb+m] and d enc[3+nb+m]/d coef_m = -2 pi enc[c] enc[3+m]:
+      // column m (m+nb) of this pass accumulates G[f][m] = sum_n dZ_0[n][f] * that derivative; k_reduce_coef contracts G with W_0.
+      const int nb = a.coef_cols;
+#pragma unroll
+      for (int c = 0; c < KMAX; ++c) {
+        const bool second = c >= nb;
+        const int m = second ? c - nb : c;
+        ev[c] = c < 2 * nb ? (second ? -6.283185307179586f : 6.283185307179586f) * e[m % 3] * e[min(second ? 3 + m : 3 + nb + m, a.k0 - 1)] : 0.f;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
       const int e8 = ENC ? 2 * sub + i : i;                   // element of the 16-byte chunk
@@ -1205,6 +1217,29 @@ __global__ void __launch_bounds__(256) k_reduce_small(const ReduceArgs a) {
   } else if (e < (size_t)F * a.k0pad + F) dst = (size_t)F * a.k0 + (e - (size_t)F * a.k0pad);
   else dst = wout + (e - (size_t)F * a.k0pad - F);       // F output weights, then the output bias
   a.grad[dst] += s;
+}
+
+// Fourier coefficients' gradient from the records of a coef_cols pass of k_small_grads_bf16:
+// d_coef[m] += sum_f W_0[f][3+m] G[f][m] + W_0[f][3+nb+m] G[f][nb+m].  grid = nb blocks of F threads; fixed summation order.
+template <int F>
+__global__ void __launch_bounds__(F) k_reduce_coef(const ReduceArgs a) {
+  __shared__ float red[F];
+  const int m = blockIdx.x, f = threadIdx.x, nb = a.coef_cols;
+  const size_t SS = (size_t)F * a.k0pad + 2 * F + 4;
+  float g1 = 0.f, g2 = 0.f;
+#pragma unroll 4
+  for (int b = 0; b < a.n_small; ++b) {
+    const float* P = a.partial_s + (size_t)b * SS + (size_t)f * a.k0pad;
+    g1 += P[m];
+    g2 += P[nb + m];
+  }
+  red[f] = fmaf(a.w0[(size_t)f * a.k0 + 3 + m], g1, a.w0[(size_t)f * a.k0 + 3 + nb + m] * g2);
+  __syncthreads();
+  for (int s = F / 2; s >= 1; s >>= 1) {
+    if (f < s) red[f] += red[f + s];
+    __syncthreads();
+  }
+  if (f == 0) a.d_coef[m] += red[0];
 }
 
 #ifndef AFX_TEMPLATES_ONLY

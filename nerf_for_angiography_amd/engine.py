@@ -3,6 +3,7 @@ works on and exposes the fused kernels to the Python mirror of the reference int
 PyTorch is used for device memory and streams only."""
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 from dataclasses import dataclass
 from typing import Optional
@@ -156,6 +157,19 @@ class Engine:
         self._check(self.lib.afx_mlp_infer(self.h, _lib.PREC[prec], _ptr(prepared), _ptr(pts), pts.shape[0], _ptr(out),
                                           int(apply_sigmoid), self._stream(dev)), "afx_mlp_infer")
         return out
+
+    @contextlib.contextmanager
+    def encoding_grad(self, flat: torch.Tensor, d_aux: Optional[torch.Tensor]):
+        """Backward calls inside this scope also accumulate d loss / d fourier coefficients into `d_aux`
+        (afx_set_encoding_grad); None: plain scope."""
+        if d_aux is None:
+            yield
+            return
+        self._check(self.lib.afx_set_encoding_grad(self.h, _ptr(flat), _ptr(d_aux)), "afx_set_encoding_grad")
+        try:
+            yield
+        finally:
+            self.lib.afx_set_encoding_grad(self.h, None, None)
 
     def mlp_backward(self, prepared, pts, d_out, grad_flat, prec: str):
         dev = prepared.device

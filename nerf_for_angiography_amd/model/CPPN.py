@@ -45,8 +45,10 @@ class _MlpFn(torch.autograd.Function):
         model = ctx.model
         (pts,) = ctx.saved_tensors
         flat_grad = torch.zeros(model.engine.param_count, dtype=torch.float32, device=pts.device)
-        model.engine.mlp_backward(model._prepared(), pts, d_out.reshape(-1).contiguous(), flat_grad, model.precision)
-        return (None, None) + model._split_grad(flat_grad)
+        coef_grad = model._coef_grad_buffer()
+        with model.engine.encoding_grad(model._flat, coef_grad):
+            model.engine.mlp_backward(model._prepared(), pts, d_out.reshape(-1).contiguous(), flat_grad, model.precision)
+        return (None, None) + model._fn_grads(flat_grad, coef_grad)
 
 
 class CPPN(nn.Module):
@@ -256,6 +258,30 @@ class CPPN(nn.Module):
             out += [lin.weight, lin.bias]
         return out
 
+    def _coef_trainable(self):
+        return self.use_pos_enc == "fourier" and self.fourier_coefficients.requires_grad
+
+    def _fn_params(self):
+        """Inputs of the autograd Functions: the Linear parameters, then the fourier coefficients when they train."""
+        return self._hip_params() + ([self.fourier_coefficients] if self._coef_trainable() else [])
+
+    def _coef_grad_buffer(self):
+        """Zeroed accumulator for d loss / d fourier_coefficients (None when they do not train); the upstream module makes
+        them an nn.Parameter (model/CPPN.py:92), so the optimiser updates them."""
+        if not self._coef_trainable():
+            return None
+        if self.precision == "f32":
+            raise NotImplementedError("trainable fourier_coefficients need a 16-bit precision of the fused kernels "
+                                      "(f16s8, f16, bf16, bf16x3); with 'f32' freeze them: "
+                                      "model.fourier_coefficients.requires_grad_(False)")
+        return torch.zeros(self.fourier_coefficients.numel(), dtype=torch.float32, device=self._flat.device)
+
+    def _fn_grads(self, flat_grad, coef_grad):
+        out = self._split_grad(flat_grad)
+        if self._coef_trainable():
+            out = out + (coef_grad.view_as(self.fourier_coefficients),)
+        return out
+
     def _split_grad(self, flat_grad):
         layout, _ = self._layout()
         out = []
@@ -271,11 +297,8 @@ class CPPN(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self.fused and x.is_cuda and x.shape[-1] == self.num_input_channels:
-            if self.use_pos_enc == "fourier" and torch.is_grad_enabled() and self.fourier_coefficients.requires_grad:
-                raise NotImplementedError("the fused kernels treat fourier_coefficients as constants: call "
-                                          "model.fourier_coefficients.requires_grad_(False) or use torch.no_grad()")
             pts = x.reshape(-1, 3).float().contiguous()
-            out = _MlpFn.apply(self, pts, *self._hip_params())
+            out = _MlpFn.apply(self, pts, *self._fn_params())
             return out.reshape(*x.shape[:-1], 1)
         return self._forward_ops(x)
 

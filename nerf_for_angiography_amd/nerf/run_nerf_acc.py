@@ -133,8 +133,8 @@ def main(argv=None):
     coarse_model = CPPN(dict(params)).to(device)
     if coarse_model.use_pos_enc == 'barf':
         coarse_model.update_barf_alpha(start_pos_enc_basis, 'pts')
-    if coarse_model.use_pos_enc == 'fourier':
-        coarse_model.fourier_coefficients.requires_grad_(False)
+    if coarse_model.use_pos_enc == 'fourier' and args.precision == 'f32':
+        coarse_model.fourier_coefficients.requires_grad_(False)     # the f32 kernels take them as constants; the 16-bit ones train them
     with torch.no_grad():
         coarse_model.output_linear[0].bias.fill_(args.out_bias_init)
     coarse_optimizer = torch.optim.Adam(list(coarse_model.parameters()), lr=coarse_lr)

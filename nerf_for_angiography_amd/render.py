@@ -43,10 +43,14 @@ class _RenderFn(torch.autograd.Function):
         model, spec = ctx.model, ctx.spec
         (pixel,) = ctx.saved_tensors
         flat_grad = torch.zeros(model.engine.param_count, dtype=torch.float32, device=pixel.device)
-        model.engine.render_backward(model._prepared(), spec, pixel, d_pixel.contiguous(), flat_grad, model.precision)
+        coef_grad = model._coef_grad_buffer()
+        with model.engine.encoding_grad(model.flat_params, coef_grad):
+            model.engine.render_backward(model._prepared(), spec, pixel, d_pixel.contiguous(), flat_grad, model.precision)
         if _grad_hook is not None:
             _grad_hook(flat_grad)
-        return (None, None, None) + model._split_grad(flat_grad)
+            if coef_grad is not None:
+                _grad_hook(coef_grad)
+        return (None, None, None) + model._fn_grads(flat_grad, coef_grad)
 
 
 def _check_model(model):
@@ -59,11 +63,9 @@ def _check_model(model):
 
 def render_spec(spec: RenderSpec, model, want_aux: bool = False) -> RenderOutput:
     _check_model(model)
-    if model.use_pos_enc == "fourier" and torch.is_grad_enabled() and model.fourier_coefficients.requires_grad:
-        raise NotImplementedError("the fused kernels treat fourier_coefficients as constants")
     if not want_aux:
-        return RenderOutput(_RenderFn.apply(model, spec, False, *model._hip_params()))
-    pixel, sigma, tau = _RenderFn.apply(model, spec, True, *model._hip_params())
+        return RenderOutput(_RenderFn.apply(model, spec, False, *model._fn_params()))
+    pixel, sigma, tau = _RenderFn.apply(model, spec, True, *model._fn_params())
     out = RenderOutput(pixel, sigma=sigma)
     if spec.mode == "dense":
         # weights / depth_map / entropy of render_volume_density (nerf_helpers.py:107-119) from the
@@ -130,18 +132,22 @@ def train_step_mse(model, spec: RenderSpec, target: torch.Tensor, n_global: Opti
         raise NotImplementedError("train_step_mse needs a 16-bit precision (f16, bf16, bf16x3); with 'f32' use render + autograd")
     n = int(n_global) if n_global else int(spec.n_rays)
     flat_grad = torch.zeros(model.engine.param_count, dtype=torch.float32, device=model.flat_params.device)
+    coef_grad = model._coef_grad_buffer()
     s_pad = (spec.n_samples + 31) // 32 * 32
-    if 256 % s_pad == 0:
-        pixel = model.engine.train_step_mse(model._prepared(), spec, target, 1.0 / n, flat_grad, model.precision)
-    else:
-        # a ray would straddle workgroup tiles (e.g. the reference's 300 samples/ray): same arithmetic in two
-        # launches - forward, then the backward kernel with dL/dpixel = 2 (pixel - target) / n
-        pixel, _, _ = model.engine.render_forward(model._prepared(), spec, model.precision)
-        d_pixel = (pixel - _as_f32(target, pixel.device)) * (2.0 / n)
-        model.engine.render_backward(model._prepared(), spec, pixel, d_pixel, flat_grad, model.precision)
+    with model.engine.encoding_grad(model.flat_params, coef_grad):
+        if 256 % s_pad == 0:
+            pixel = model.engine.train_step_mse(model._prepared(), spec, target, 1.0 / n, flat_grad, model.precision)
+        else:
+            # a ray would straddle workgroup tiles (e.g. the reference's 300 samples/ray): same arithmetic in two
+            # launches - forward, then the backward kernel with dL/dpixel = 2 (pixel - target) / n
+            pixel, _, _ = model.engine.render_forward(model._prepared(), spec, model.precision)
+            d_pixel = (pixel - _as_f32(target, pixel.device)) * (2.0 / n)
+            model.engine.render_backward(model._prepared(), spec, pixel, d_pixel, flat_grad, model.precision)
     if _grad_hook is not None:
         _grad_hook(flat_grad)
-    for p, g in zip(model._hip_params(), model._split_grad(flat_grad)):
+        if coef_grad is not None:
+            _grad_hook(coef_grad)
+    for p, g in zip(model._fn_params(), model._fn_grads(flat_grad, coef_grad)):
         if p.grad is None:
             p.grad = g
         else:

@@ -481,6 +481,66 @@ def test_barf_backward_vs_oracle(prec):
         assert rel_l2(got[k], v.numpy()) < TOL[prec]["grad"], k
 
 
+@pytest.mark.parametrize("prec", ["bf16x3", "f16", "bf16"])
+def test_fourier_coefficients_train(prec):
+    """model/CPPN.py:92 makes fourier_coefficients an nn.Parameter, so the reference's Adam updates them: their gradient
+    (second pass of the first-layer kernel against d enc / d coef) vs the oracle's autograd, through the three backward
+    entry points (render + autograd, fused train step, points mode)."""
+    from oracle import angio_oracle as orc
+    from nerf_for_angiography_amd.render import render_rays, train_step_mse
+    from nerf_for_angiography_amd.engine import RenderSpec
+    torch.manual_seed(13)
+    m = make_model(4, 64, "fourier", precision=prec)
+    with torch.no_grad():
+        m.fourier_coefficients.mul_(0.1)          # sigma 0.5: arguments of a few radians on a unit-scale scene
+        m.output_linear[0].weight.mul_(4.0)
+        m.output_linear[0].bias.fill_(-4.0)
+    r, s = 256, 32
+    o = torch.tensor([[0.0, 0.0, 1.5]]).repeat(r, 1) + torch.randn(r, 3) * 0.01
+    d = torch.nn.functional.normalize(torch.randn(r, 3) * 0.2 + torch.tensor([0, 0, -1.0]), dim=-1)
+    tgt = torch.rand(r)
+    cfg = dict(num_early_layers=4, num_filters=64, pos_enc="fourier", pos_enc_basis=5)
+    params = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    pix_c, _, grads_c = orc.loss_and_grads(o, d, tgt, cfg, params, near=0.5, far=2.5, n_samples=s, convention="acc")
+    assert "fourier_coefficients" in grads_c
+    want = grads_c["fourier_coefficients"].numpy()
+    tol = 2 * TOL[prec]["grad"]
+
+    out = render_rays(m, o.to(DEV), d.to(DEV), s, 0.5, 2.5, mode="acc")
+    torch.nn.functional.mse_loss(out.rgb_map, tgt.to(DEV)).backward()
+    assert rel_l2(out.rgb_map.detach().cpu().numpy(), pix_c.numpy()) < TOL[prec]["pix"]
+    got = _grads_by_name(m)
+    for k, v in grads_c.items():
+        assert rel_l2(got[k], v.numpy()) < tol, k
+    g_autograd = m.fourier_coefficients.grad.detach().cpu().numpy().copy()
+
+    # the fused train step accumulates the same gradient into .grad
+    m.zero_grad(set_to_none=True)
+    spec = RenderSpec(n_rays=r, n_samples=s, origins=o.to(DEV), dirs=d.to(DEV), mode="acc", t_near=0.5, t_far=2.5)
+    train_step_mse(m, spec, tgt.to(DEV))
+    assert rel_l2(m.fourier_coefficients.grad.cpu().numpy(), want) < tol
+    assert rel_l2(m.fourier_coefficients.grad.cpu().numpy(), g_autograd) < TOL[prec]["grad"]      # bf16x3: the train step renders with the backward kernel's own forward
+
+    # points mode: d(sum c_p raw_p)/d coef
+    m.zero_grad(set_to_none=True)
+    pts = (torch.rand(1000, 3) * 2 - 1)
+    c = torch.randn(1000, 1)
+    (m(pts.to(DEV)) * c.to(DEV)).sum().backward()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in params.items() if v.dtype.is_floating_point}
+    (orc.cppn_forward(pts, cfg, {**params, **leaves}) * c).sum().backward()
+    # random-sign cotangents: the sum cancels to ~1/sqrt(P) of its terms, which magnifies the operand rounding (f16: 2.2e-2)
+    assert rel_l2(m.fourier_coefficients.grad.cpu().numpy(), leaves["fourier_coefficients"].grad.numpy()) < 2 * tol
+
+    # frozen coefficients: no gradient, and the f32 kernels refuse to train them
+    m.fourier_coefficients.requires_grad_(False)
+    m.zero_grad(set_to_none=True)
+    render_rays(m, o.to(DEV), d.to(DEV), s, 0.5, 2.5, mode="acc").rgb_map.sum().backward()
+    assert m.fourier_coefficients.grad is None
+    m32 = make_model(4, 64, "fourier", precision="f32")
+    with pytest.raises(NotImplementedError):
+        render_rays(m32, o.to(DEV), d.to(DEV), s, 0.5, 2.5, mode="acc").rgb_map.sum().backward()
+
+
 @pytest.mark.parametrize("prec", ["f32", "bf16x3"])
 def test_hierarchical_coarse_fine_vs_oracle(prec):
     """Config-C3 style pipeline: coarse dense render -> weights -> sample_pdf/merge (afx_fine_depths) -> fine render
