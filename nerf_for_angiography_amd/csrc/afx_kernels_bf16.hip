@@ -19,6 +19,7 @@
 //   the compositing run in fp32 on the VALU.
 #include <hip/hip_runtime.h>
 #include <type_traits>
+#include <utility>
 #include "afx_internal.h"
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -97,6 +98,29 @@ __device__ __forceinline__ u32x4 to_bf8x16(u32x4 a, u32x4 b, float scale) {
   }
   return r;
 }
+// one packed f16 pair -> two bf8 bytes in the low (HI = false) or high half of `acc` (the builtin wants HI as a constant)
+template <bool HI> __device__ __forceinline__ unsigned bf8_pair(unsigned acc, unsigned pair) {
+  if (HI) asm("v_cvt_scalef32_pk_bf8_f16 %0, %1, 1.0 op_sel:[0,0,1]" : "+v"(acc) : "v"(pair));
+  else asm("v_cvt_scalef32_pk_bf8_f16 %0, %1, 1.0" : "+v"(acc) : "v"(pair));
+  return acc;
+}
+// one v_pk_mul_f16 on dwords.  (asm: hipcc 7.2 miscompiles f16x2 arithmetic on bit-cast elements of a u32x4 - it folds the
+// element index away, see k_wgrad_bf16 - and the gap schedule wants exactly one instruction per slot anyway)
+__device__ __forceinline__ unsigned pk_mul_f16(unsigned a, unsigned b) {
+  unsigned r;
+  asm("v_pk_mul_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// compile-time unrolled loop: f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N - 1>)
+template <int... I, class Fn> __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, Fn&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N_, class Fn> __device__ __forceinline__ void static_for(Fn&& f) { static_for_impl(std::make_integer_sequence<int, N_>{}, f); }
+// AFX_GAPS=1 (build.py --variant=gaps): the MFMA-gap schedule of the 8-bit-stash backward kernel, kept for A/B.  It measured
+// 3 ms SLOWER per step than the plain order, with real and with all-zero operands, so the default is off.
+#ifndef AFX_GAPS
+#define AFX_GAPS 0
+#endif
 // stash position -> feature for the 8-bit layout (a permutation inside each block of 32)
 __device__ __forceinline__ int fperm8(int p) {
   const int hh = (p >> 4) & 1, s2 = (p >> 3) & 1, j = p & 7;
@@ -268,7 +292,32 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
   // Raw s_barrier: __syncthreads() would re-insert vmcnt(0).
   constexpr int WAITN = (BWD ? PD * SPS : 0) + (PD - 1) * (PIECES0 < PIECESH ? PIECES0 : PIECESH);
   // `counted` = false: the previous step issued no stash stores (SG: the last forward layer's H_N is not stashed)
-  auto step_begin = [&](bool counted = true) -> const char* {
+  // GAPS (8-bit stash kernel): stash stores move between tiles, so the wave counts them; a step that issued fewer than SPS
+  // behind its request is followed by a full wait (wave-uniform scalar counter).
+  constexpr bool GAPS = S8 && AFX_GAPS;
+  constexpr int IPG = 16 / (2 * NT);     // work items per MFMA gap (GAPS)
+  int nstores = 0;
+  // GAPS: a hidden step's request is issued piece by piece in the first MFMA gaps of the step's first tile (defer = true):
+  // issued in one burst behind the barrier, the 8 waves' pieces queue in the vector-memory path and every wave sits in that
+  // queue before its first MFMA (12-20 % of the waves' cycles in the stamp build).  All pieces precede the step's stores.
+  bool req_pending = false;
+  auto request_piece = [&](int i) {
+    char* dst = slot0 + wslot * SLOT;
+    const uint32_t off = (uint32_t)i * (NW * 1024u);
+    if (cpos < SPL ? i < PIECES0 : i < PIECESH)
+      __builtin_amdgcn_global_load_lds(GPTR(wnext + off + voff), LPTR(dst + off + wave * 1024), 16, 0, 0);
+  };
+  auto request_end = [&]() {
+    wnext += cpos < SPL ? STEP0 : STEPH;
+    if (++cpos == steps_per_tile) { cpos = 0; wnext = a.stream_fwd; }
+    wslot = wslot + 1 == RING ? 0 : wslot + 1;
+    --to_issue;
+    nstores = 0;
+    req_pending = false;
+  };
+  static_assert(!GAPS || (PIECES0 <= PIECESH && PIECESH <= 2 * NT && (PIECESH - 1) * IPG < 7), "GAPS: the request's pieces precede the first stash store");
+  auto step_begin = [&](bool counted = true, bool defer = false) -> const char* {
+    if constexpr (GAPS) counted = nstores >= SPS;
 #ifdef AFX_SAFE_WAITS
     counted = false;
 #endif
@@ -281,7 +330,10 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
       asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
       STAMP(1);
     }
-    if (to_issue > 0) request();
+    if (to_issue > 0) {
+      if (GAPS && defer) req_pending = true;
+      else { request(); nstores = 0; }
+    }
     STAMP(2);
     const char* cur = slot0 + rslot * SLOT;
     rslot = rslot + 1 == RING ? 0 : rslot + 1;
@@ -358,7 +410,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
 #pragma unroll
         for (int q = 0; q < 8; ++q) p[q] = relu2(pack2t<H16>(acc[2 * q], acc[2 * q + 1]));
         if (bt >= 0) acc = bias_init(bl, bt);
-        if (BWD) {
+        if (BWD && !(GAPS && (l >= 1 || t == NT - 1))) {
           unsigned bits = nz2(p[0], one2);
 #pragma unroll
           for (int q = 1; q < 8; ++q) bits |= nz2(p[q], one2) << q;
@@ -376,8 +428,10 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
           }
         }
         if constexpr (S8) {
-          if (l != N)       // one 16-byte store per tile: chunk 2t + h of the 8-bit layout
+          if (l != N && !(GAPS && (l >= 1 || t == NT - 1))) {     // one 16-byte store per tile: chunk 2t + h of the 8-bit layout
+            ++nstores;
             stash_store((char*)a.stash_h + (size_t)l * a.stash_rows * F + (so[cg] + (uint32_t)(2 * t) * 512u), to_bf8x16(nf[0], nf[1], 1.0f));
+          }
         }
         // the reloaded bias is waited for HERE (it has long landed), not by an lgkmcnt(0) behind the next tile's first
         // fragment reads, which would expose their round trip at every tile start
@@ -386,36 +440,42 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
     };
 
     // Backward kernel: acc[cg] += W_tile . B with a rolling PF-deep fragment prefetch and hand-counted LDS waits.
-    auto rolling_mma_impl = [&](auto pf_c, const u32x4* sl, u32x4 (*bh)[NT][2], f32x16* acc) {
+    // `gap(u)` (u a std::integral_constant): independent VALU / store work issued between MFMA u and MFMA u + 1.  The MFMAs of
+    // a tile form one dependent chain (same accumulator), so the wave's issue slots between them are free; the partner wave
+    // of the SIMD runs the same phase at the same time (the step barrier keeps the pair in lockstep), so work that sits in
+    // front of or behind the loop leaves the matrix pipe idle for both.
+    auto no_gap = [](auto) {};
+    auto rolling_mma_impl = [&](auto pf_c, const u32x4* sl, u32x4 (*bh)[NT][2], f32x16* acc, auto&& gap) {
       constexpr int PF = decltype(pf_c)::value;
       static_assert(PF >= 1 && PF <= 5 && PF <= 2 * NT, "the tail waits below cover PF <= 5");
       const uint32_t la = (uint32_t)(uintptr_t)LPTR(sl) + (uint32_t)lane * 16u;
       u32x4 ar[PF];
 #pragma unroll
       for (int i = 0; i < PF; ++i) lds_read_frag(ar[i], la, i * 1024);
-#pragma unroll
-      for (int u = 0; u < 2 * NT; ++u) {
+      static_for<2 * NT>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
         // younger reads outstanding behind fragment u: min(PF - 1, 2 NT - 1 - u)
-        if (2 * NT - 1 - u >= PF - 1) lds_wait_frag<PF - 1>(ar[u % PF]);
-        else if (2 * NT - 1 - u == 3) lds_wait_frag<3>(ar[u % PF]);
-        else if (2 * NT - 1 - u == 2) lds_wait_frag<2>(ar[u % PF]);
-        else if (2 * NT - 1 - u == 1) lds_wait_frag<1>(ar[u % PF]);
+        if constexpr (2 * NT - 1 - u >= PF - 1) lds_wait_frag<PF - 1>(ar[u % PF]);
+        else if constexpr (2 * NT - 1 - u == 3) lds_wait_frag<3>(ar[u % PF]);
+        else if constexpr (2 * NT - 1 - u == 2) lds_wait_frag<2>(ar[u % PF]);
+        else if constexpr (2 * NT - 1 - u == 1) lds_wait_frag<1>(ar[u % PF]);
         else lds_wait_frag<0>(ar[u % PF]);
         const u32x4 ah = ar[u % PF];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int cg = 0; cg < NCG; ++cg) acc[cg] = mfma_t<H16>(ah, bh[cg][u >> 1][u & 1], acc[cg]);
-        if (u + PF < 2 * NT) lds_read_frag(ar[u % PF], la, (u + PF) * 1024);
+        if constexpr (u + PF < 2 * NT) lds_read_frag(ar[u % PF], la, (u + PF) * 1024);
+        gap(uc);
         __builtin_amdgcn_sched_barrier(0);
-      }
+      });
     };
 
     // One hidden-layer tile: acc[cg] += W_tile . B over all 2*NT k-steps.  A fragments are read from the
     // slab in groups of G k-steps, two groups in flight (explicit software pipeline; sched_barrier keeps
     // hipcc from sinking the reads back next to their MFMAs), so LDS latency hides behind >= G MFMAs.
-    auto mma_step = [&](const u32x4* sl, const u32x4* sll, u32x4 (*bh)[NT][2], u32x4 (*bl)[X3 ? NT : 1][2], f32x16* acc) {
+    auto mma_step = [&](const u32x4* sl, const u32x4* sll, u32x4 (*bh)[NT][2], u32x4 (*bl)[X3 ? NT : 1][2], f32x16* acc, auto&& gap) {
       if (BWD) {      // (forward-only kernels: the grouped reads below measure the same, 26.4 vs 26.5 ms)
-        rolling_mma_impl(std::integral_constant<int, AFX_PF_FWD>{}, sl, bh, acc);
+        rolling_mma_impl(std::integral_constant<int, AFX_PF_FWD>{}, sl, bh, acc, gap);
         return;
       }
       constexpr int G = (X3 || NW == 8) ? 2 : 4;
@@ -488,13 +548,47 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
       f32x16 accp[NCG];
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        if (t % TPS == 0) stepbase = step_begin(!(SG && l == N && t > 0));
+        if (t % TPS == 0) stepbase = step_begin(!(SG && l == N && t > 0), true);
         const u32x4* sl = (const u32x4*)(stepbase + (t % TPS) * SLABT);             // hi block [u*64 + lane]
         const u32x4* sll = (const u32x4*)(stepbase + STEPH + (t % TPS) * SLABT);    // lo block (X3)
         f32x16 acc[NCG];
 #pragma unroll
         for (int cg = 0; cg < NCG; ++cg) acc[cg] = BWD ? accn[cg] : bias_init(l, t);
-        mma_step(sl, sll, hs, hsl, acc);
+        if constexpr (GAPS) {
+          // The part of a forward tile's epilogue that needs only its packed activations - ReLU mask bits, 8-bit stash - is
+          // issued in the gaps of the NEXT tile's MFMA loop: tile (l, t-1), or the previous layer's last tile at t == 0.
+          static_assert(NCG == 1, "");
+          const int pl = t > 0 ? l : l - 1, pt = t > 0 ? t - 1 : NT - 1;
+          const u32x4* pfr = t > 0 ? hd[0][t - 1] : hs[0][NT - 1];
+          unsigned bits = 0, r[4];
+          mma_step(sl, sll, hs, hsl, acc, [&](auto uc) {
+            if constexpr (decltype(uc)::value < PIECESH) {
+              if (t % TPS == 0 && req_pending) {
+                request_piece(decltype(uc)::value);
+                if constexpr (decltype(uc)::value == PIECESH - 1) request_end();
+              }
+            }
+            static_for<IPG>([&](auto kc) {       // 16 work items over the 2 NT gaps
+              constexpr int j = decltype(uc)::value * IPG + decltype(kc)::value;
+              if constexpr (j < 8) {
+                const unsigned z = nz2(pfr[j >> 2][j & 3], one2);
+                bits = j == 0 ? z : (bits | (z << j));
+              } else {
+                constexpr int i = j - 8;
+                r[i >> 1] = bf8_pair<(i & 1) != 0>((i & 1) ? r[i >> 1] : 0u, pfr[i >> 2][i & 3]);
+              }
+              if constexpr (j == 15) {
+                if (pl != N) {
+                  ++nstores;
+                  stash_store((char*)a.stash_h + (size_t)pl * a.stash_rows * F + (so[0] + (uint32_t)(2 * pt) * 512u), (u32x4){r[0], r[1], r[2], r[3]});
+                }
+              }
+            });
+          });
+          mk16[((pl * NT + pt) * NCG) * NTH + tid] = (unsigned short)(bits | (bits >> 8));
+        } else {
+          mma_step(sl, sll, hs, hsl, acc, no_gap);
+        }
         if (DEFER) {
           if (t > 0) {
 #pragma unroll
@@ -519,6 +613,14 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
 #pragma unroll
         for (int cg = 0; cg < NCG; ++cg)
           epilogue(l, NT - 1, accp[cg], cg, hd[cg][NT - 1], hdl[X3 ? cg : 0][X3 ? NT - 1 : 0]);
+      }
+      if constexpr (GAPS) {
+        if (l == N) {      // nothing follows the last layer's last tile: its mask bits here (H_N is not stashed)
+          unsigned bits = nz2(hd[0][NT - 1][0][0], one2);
+#pragma unroll
+          for (int q = 1; q < 8; ++q) bits |= nz2(hd[0][NT - 1][q >> 2][q & 3], one2) << q;
+          mk16[((N * NT + NT - 1) * NCG) * NTH + tid] = (unsigned short)(bits | (bits >> 8));
+        }
       }
     };
     {
@@ -676,7 +778,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
           }
         }
       }
-      auto mma_step_plain = [&](const u32x4* sl, u32x4 (*bh)[NT][2], f32x16* acc) { rolling_mma_impl(std::integral_constant<int, AFX_PF_BWD>{}, sl, bh, acc); };
+      auto mma_step_plain = [&](const u32x4* sl, u32x4 (*bh)[NT][2], f32x16* acc) { rolling_mma_impl(std::integral_constant<int, AFX_PF_BWD>{}, sl, bh, acc, no_gap); };
       auto stash_dz_tile = [&](int l, int t) {
 #pragma unroll
         for (int cg = 0; cg < NCG; ++cg) {
@@ -693,13 +795,14 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
           }
         }
       };
+      unsigned pk[8], mwprev = 0;      // GAPS: the previous tile's packed, not yet masked input gradients and its mask word
       for (int l = N; l >= 1; --l) {
         u32x4 dn[NCG][NT][2];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          if (t % TPS == 0) stepbase = step_begin(!(SG && l == N && t == 0));
+          if (t % TPS == 0) stepbase = step_begin(!(SG && l == N && t == 0), true);
           const u32x4* sl = (const u32x4*)(stepbase + (t % TPS) * SLABT);
-          stash_dz_tile(l, t);                   // SPS stores per step, after the step's request
+          if constexpr (!GAPS) stash_dz_tile(l, t);                   // SPS stores per step, after the step's request
           f32x16 acc[NCG];
           unsigned mw[NCG];                      // ReLU mask words, read ahead of the MFMA loop
 #pragma unroll
@@ -707,17 +810,62 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
             acc[cg] = (f32x16){0.f};
             mw[cg] = mk16[(((l - 1) * NT + t) * NCG + cg) * NTH + tid];
           }
-          mma_step_plain(sl, dz, acc);
-          STAMP(5);
-  #pragma unroll
-          for (int cg = 0; cg < NCG; ++cg) {
-            // dZ_{l-1} = dH_{l-1} masked by ReLU'(Z_{l-1}): round to bf16, AND the pairs with their half masks
-            const unsigned b32 = mask_expand(mw[cg]);
+          if constexpr (GAPS) {
+            // in the gaps of this tile's MFMA chain: the 8-bit stash of dZ'_l tile t (scale by g_hat, convert, store) and the
+            // ReLU masking of the previous tile's result; behind the loop only the fp32 -> f16 packing of this tile is left
+            unsigned r[4];
+            const unsigned b32p = mask_expand(mwprev);
+            rolling_mma_impl(std::integral_constant<int, AFX_PF_BWD>{}, sl, dz, acc, [&](auto uc) {
+              if constexpr (decltype(uc)::value < PIECESH) {
+                if (t % TPS == 0 && req_pending) {
+                  request_piece(decltype(uc)::value);
+                  if constexpr (decltype(uc)::value == PIECESH - 1) request_end();
+                }
+              }
+              static_for<IPG>([&](auto kc) {
+                constexpr int j = decltype(uc)::value * IPG + decltype(kc)::value;
+                if constexpr (j < 8) {
+                  const unsigned x = pk_mul_f16(dz[0][t][j >> 2][j & 3], ghat2[0]);
+                  r[j >> 1] = bf8_pair<(j & 1) != 0>((j & 1) ? r[j >> 1] : 0u, x);
+                  if constexpr (j == 7) {
+                    ++nstores;
+                    stash_store((char*)a.stash_dz + (size_t)l * a.stash_rows * F + (so[0] + (uint32_t)(2 * t) * 512u), (u32x4){r[0], r[1], r[2], r[3]});
+                  }
+                } else if (t > 0) {
+                  constexpr int q = j - 8;
+                  pk[q] &= halfmask(b32p, q);
+                  if constexpr (j == 15) {
+                    dn[0][t > 0 ? t - 1 : 0][0] = (u32x4){pk[0], pk[1], pk[2], pk[3]};
+                    dn[0][t > 0 ? t - 1 : 0][1] = (u32x4){pk[4], pk[5], pk[6], pk[7]};
+                  }
+                }
+              });
+            });
+            STAMP(5);
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
-              dn[cg][t][q >> 2][q & 3] = pack2t<H16>(acc[cg][2 * q], acc[cg][2 * q + 1]) & halfmask(b32, q);
+            for (int q = 0; q < 8; ++q) pk[q] = pack2t<H16>(acc[0][2 * q], acc[0][2 * q + 1]);
+            mwprev = mw[0];
+            if (t == NT - 1) {
+              const unsigned b32 = mask_expand(mw[0]);
+#pragma unroll
+              for (int q = 0; q < 8; ++q) pk[q] &= halfmask(b32, q);
+              dn[0][t][0] = (u32x4){pk[0], pk[1], pk[2], pk[3]};
+              dn[0][t][1] = (u32x4){pk[4], pk[5], pk[6], pk[7]};
+            }
+            STAMP(6);
+          } else {
+            mma_step_plain(sl, dz, acc);
+            STAMP(5);
+#pragma unroll
+            for (int cg = 0; cg < NCG; ++cg) {
+              // dZ_{l-1} = dH_{l-1} masked by ReLU'(Z_{l-1}): round to bf16, AND the pairs with their half masks
+              const unsigned b32 = mask_expand(mw[cg]);
+#pragma unroll
+              for (int q = 0; q < 8; ++q)
+                dn[cg][t][q >> 2][q & 3] = pack2t<H16>(acc[cg][2 * q], acc[cg][2 * q + 1]) & halfmask(b32, q);
+            }
+            STAMP(6);
           }
-          STAMP(6);
         }
 #pragma unroll
         for (int cg = 0; cg < NCG; ++cg)
