@@ -249,6 +249,16 @@ def main():
                 roofline["algorithmic_bytes_per_launch"] = float(stash_bytes * per_launch_samples)
         except Exception:
             pass
+    # the dominant kernel is power-limited under real data (tools/power_probe.py): its time with all-zero operands, same binary
+    probe_file = os.path.join(ROOT, "profiles", "r02_power_probe.json")
+    if default_cfg and args.precision == "f16s8" and os.path.exists(probe_file):
+        try:
+            pz = json.load(open(probe_file))["plain_order (default build)"]
+            roofline["power_note"] = {"chain_bwd_ms_per_step_real_data": pz["seeded"]["chain_bwd_ms"],
+                                      "chain_bwd_ms_per_step_zero_operands": pz["zero"]["chain_bwd_ms"],
+                                      "source": "profiles/r02_power_probe.json (committed measurement, not this run)"}
+        except Exception:
+            pass
 
     result = {"metric": "ray-samples/sec (fwd+bwd)", "value": round(value, 1), "unit": "ray-samples/s",
               "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
