@@ -2,7 +2,7 @@
 """Dev probe (GPU): errors of each precision mode against the golden fixtures / CPU oracle, to set test tolerances."""
 import os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import rel_l2
 from oracle import angio_oracle as orc

@@ -2,11 +2,11 @@
 """Operand-precision study on the CPU (no GPU, no reference import): what the forward pixel error and the hidden-layer
 weight-gradient error of the 8x256 benchmark model would be for different operand / stash formats, emulated by rounding the
 operands of every contraction to the format and accumulating in fp32 (what an MFMA does).  Used to choose the training
-precision of round 2; not part of the product or of the tests."""
+precision of round 2; test-side tooling (it imports the oracle), not collected by pytest."""
 import sys, os, math
 import numpy as np
 import torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from oracle import angio_oracle as orc
 
 torch.manual_seed(0)
