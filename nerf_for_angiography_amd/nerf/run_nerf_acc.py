@@ -219,7 +219,7 @@ def main(argv=None):
             mse = torch.nn.functional.mse_loss(pred_img, test_img)
             psnr = float(-10. * torch.log10(mse))
             vessel_psnr = float(-10. * torch.log10(torch.nn.functional.mse_loss(test_pred[vessel], test_img[test_x, test_y][vessel])))
-            rec = dict(iter=n_iter, train_loss=float(loss_coarse), train_psnr=float(-10. * torch.log10(loss_coarse)),
+            rec = dict(iter=n_iter, train_loss=float(loss_coarse.detach()), train_psnr=float(-10. * torch.log10(loss_coarse.detach())),
                        test_psnr=psnr, test_vessel_psnr=vessel_psnr, lr=new_lr_coarse,
                        barf_alpha=float(getattr(coarse_model, 'barf_alpha', 0.0)), sec=round(time.time() - t_last, 3),
                        it_per_s=round(display_every / max(time.time() - t_last, 1e-9), 1) if n_iter else 0.0,
@@ -242,7 +242,7 @@ def main(argv=None):
                 break
     log.close()
     return dict(history=history, best_psnr=highest_psnr, best_iter=highest_iter, model=coarse_model,
-                test_image=test_img, log_dir=args.log_dir)
+                optimizer=coarse_optimizer, test_image=test_img, log_dir=args.log_dir)
 
 
 if __name__ == "__main__":

@@ -481,7 +481,7 @@ def test_barf_backward_vs_oracle(prec):
         assert rel_l2(got[k], v.numpy()) < TOL[prec]["grad"], k
 
 
-@pytest.mark.parametrize("prec", ["bf16x3", "f16", "bf16"])
+@pytest.mark.parametrize("prec", ["bf16x3", "f16", "f16s8", "bf16"])
 def test_fourier_coefficients_train(prec):
     """model/CPPN.py:92 makes fourier_coefficients an nn.Parameter, so the reference's Adam updates them: their gradient
     (second pass of the first-layer kernel against d enc / d coef) vs the oracle's autograd, through the three backward
@@ -871,6 +871,22 @@ def test_training_driver_runs_and_checkpoints(tmp_path):
         with torch.no_grad():
             assert torch.equal(m2(x), out["model"](x))
     assert len((tmp_path / "run" / "train_log.jsonl").read_text().splitlines()) == 3
+
+
+def test_training_driver_trains_fourier_coefficients(tmp_path):
+    """--pos_enc fourier: the coefficients are an optimiser parameter as upstream (model/CPPN.py:92) and move during training."""
+    from nerf_for_angiography_amd.nerf.run_nerf_acc import main
+    out = main(["--synthetic", "--img_size", "20", "--number_angles", "1", "--limited_size", "90", "--n_iters", "40",
+                "--display_every", "40", "--sample_size", "16", "--depth_samples", "64", "--num_layers", "4",
+                "--num_hidden_units", "64", "--pos_enc", "fourier", "--log_dir", str(tmp_path / "run")])
+    m = out["model"]
+    assert m.fourier_coefficients.requires_grad
+    ck = torch.load(str(tmp_path / "run" / "coarsemodel.pth"), weights_only=False)
+    assert "fourier_coefficients" in ck["model"]
+    assert any(p is m.fourier_coefficients for g in out["optimizer"].param_groups for p in g["params"])
+    state = out["optimizer"].state[m.fourier_coefficients]
+    assert int(state["step"]) >= 40 and float(state["exp_avg_sq"].sum()) > 0      # Adam has seen non-zero gradients
+    assert all(np.isfinite(r["train_loss"]) for r in out["history"])
 
 
 @pytest.mark.parametrize("type_ct", [True, False])
