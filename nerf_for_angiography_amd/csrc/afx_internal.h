@@ -13,7 +13,9 @@ constexpr int GROUP = 32;            // samples per wave column group; s_pad is 
 // piece per wave of an 8-wave workgroup); a ring of RING slots is requested RING-1 steps ahead.  Forward-only
 // kernels: 2 slots of 4 tiles.  Backward kernel: its ReLU masks fill half the LDS: 2 slots of 2 tiles (a 4-slot
 // ring of one-tile steps, requested 3 steps ahead, measured 5 ms slower per 512^2x128 step: twice the barriers).
-constexpr int chain_tps(int nt, bool bwd, bool x3) { return (nt >= 4 && !bwd && !x3) ? 4 : (nt >= 2 ? 2 : 1); }
+// tiles per step: 4 in the forward-only kernels and, at width 128 (a layer is 4 tiles, its slabs 32 KiB), also in the backward kernel -
+// one barrier per layer; at width 256 the backward kernel's ReLU masks leave LDS room for 2-tile steps only
+constexpr int chain_tps(int nt, bool bwd, bool x3) { return (nt >= 4 && !x3 && (!bwd || nt == 4)) ? 4 : (nt >= 2 ? 2 : 1); }
 constexpr int chain_ring(bool bwd) { return 2; }
 constexpr uint32_t chain_slab0_bytes(int nk0) { return ((uint32_t)nk0 * 2048u + 4095u) / 4096u * 4096u; }
 constexpr uint32_t chain_slot_bytes(int nt, int nk0, bool bwd, bool x3) {
