@@ -260,6 +260,13 @@ int afx_march_compact(const uint8_t* keep, const int64_t* offsets_in, const int6
                       const float* t_starts_in, const float* t_ends_in, int32_t* ray_indices_out, float* t_starts_out,
                       float* t_ends_out, void* stream);
 
+/* Indices of the k largest of keys[n] (ties: lowest index first), written in ASCENDING INDEX order - the selection step of the
+ * weighted ray sampler (the batch of nerf/nerf_helpers.py:137-150 is a set; its order carries no meaning).  Radix select:
+ * three histogram passes + a counted compaction, deterministic, no full sort.  workspace: afx_topk_workspace_bytes(n) bytes
+ * of device memory; n < 2^32. */
+size_t afx_topk_workspace_bytes(int64_t n);
+int afx_topk_indices(const float* keys, int64_t n, int64_t k, int64_t* out_idx, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- Device-resident ray batches (sample_pixel_rays, nerf/nerf_helpers.py:137-150: weighted sampling without
  * replacement over all pixels of all training projections).  keys[i] = log(u_i) / w_i (Efraimidis-Spirakis): the k
  * largest keys are a weighted sample without replacement; u[n] supplied, or NULL: Philox stream (seed, stream_id).

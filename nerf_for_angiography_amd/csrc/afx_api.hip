@@ -904,6 +904,40 @@ extern "C" int afx_sample_keys(const float* weights, int64_t n, const float* u, 
   return AFX_OK;
 }
 
+extern "C" size_t afx_topk_workspace_bytes(int64_t n) {
+  const int64_t nb = (n + SEL_PER_BLOCK - 1) / SEL_PER_BLOCK;
+  return (size_t)SEL_BINS * 4 + 256 + (size_t)2 * (nb > 0 ? nb : 1) * 4;
+}
+
+extern "C" int afx_topk_indices(const float* keys, int64_t n, int64_t k, int64_t* out_idx, void* workspace, size_t workspace_bytes,
+                                void* stream) {
+  if (k == 0) return AFX_OK;
+  if (n <= 0 || k < 0 || k > n || n >= ((int64_t)1 << 32)) return fail(AFX_E_INVALID, "afx_topk_indices: need 0 <= k <= n < 2^32");
+  if (!keys || !out_idx || !workspace) return fail(AFX_E_INVALID, "afx_topk_indices: null argument");
+  if (workspace_bytes < afx_topk_workspace_bytes(n)) return fail(AFX_E_WORKSPACE, "afx_topk_indices: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t nb = (n + SEL_PER_BLOCK - 1) / SEL_PER_BLOCK;
+  uint32_t* hist = (uint32_t*)workspace;
+  SelState* state = (SelState*)((char*)workspace + SEL_BINS * 4);
+  uint32_t* cnt_gt = (uint32_t*)((char*)workspace + SEL_BINS * 4 + 256);
+  uint32_t* cnt_eq = cnt_gt + nb;
+  int hb = (int)((n + 256 * 16 - 1) / (256 * 16));      // ~16 keys per thread in the histogram passes
+  if (hb < 1) hb = 1;
+  if (hb > 2048) hb = 2048;
+  hipLaunchKernelGGL(k_sel_init, dim3(1), dim3(256), 0, st, state, (uint32_t)k, hist);
+  const int shifts[3] = {21, 10, 0};
+  const uint32_t binmask[3] = {0x7ffu, 0x7ffu, 0x3ffu}, himask[3] = {0u, 0xffe00000u, 0xfffffc00u};
+  for (int p = 0; p < 3; ++p) {
+    hipLaunchKernelGGL(k_sel_hist, dim3(hb), dim3(256), 0, st, keys, n, state, himask[p], shifts[p], binmask[p], hist);
+    hipLaunchKernelGGL(k_sel_scan, dim3(1), dim3(256), 0, st, hist, state, shifts[p]);
+  }
+  hipLaunchKernelGGL(k_sel_count, dim3((unsigned)nb), dim3(256), 0, st, keys, n, state, cnt_gt, cnt_eq);
+  hipLaunchKernelGGL(k_sel_offsets, dim3(1), dim3(1024), 0, st, cnt_gt, cnt_eq, nb);
+  hipLaunchKernelGGL(k_sel_write, dim3((unsigned)nb), dim3(256), 0, st, keys, n, state, cnt_gt, cnt_eq, k, out_idx);
+  HIPCHK(hipGetLastError());
+  return AFX_OK;
+}
+
 extern "C" int afx_gather_rays(const float* origins, const float* dirs, const float* pixels, const int64_t* idx, int64_t k,
                                float* origins_out, float* dirs_out, float* pixels_out, void* stream) {
   if (k <= 0) return AFX_OK;

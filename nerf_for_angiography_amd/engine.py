@@ -479,9 +479,27 @@ def march_visibility(raw, ts, te, offsets, early_stop_eps, alpha_thre, is_alpha=
     return ri2, ts2, te2
 
 
+def topk_indices(keys: torch.Tensor, k: int) -> torch.Tensor:
+    """Indices (int64, ascending) of the k largest keys - afx_topk_indices: radix select, deterministic, no full sort."""
+    lib = _lib.load()
+    if keys.device.type != "cuda":
+        raise AfxError("topk_indices: keys must live on a GPU; there is no CPU fallback")
+    keys = keys.contiguous()
+    n = keys.numel()
+    if not 0 <= k <= n:
+        raise ValueError(f"topk_indices: k = {k} outside [0, {n}]")
+    out = torch.empty(int(k), dtype=torch.int64, device=keys.device)
+    if k == 0:
+        return out
+    nbytes = int(lib.afx_topk_workspace_bytes(n))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=keys.device)
+    _lib.check(lib.afx_topk_indices(_ptr(keys), n, int(k), _ptr(out), _ptr(ws), nbytes, Engine._stream(keys.device)), "afx_topk_indices")
+    return out
+
+
 def sample_rays(origins, dirs, pixels, weights, k, u=None, seed=0, stream_id=0):
     """Weighted sample WITHOUT replacement of k rows of a device-resident ray table (sample_pixel_rays, nerf_helpers.py:137-150):
-    Efraimidis-Spirakis keys log(u)/w, top-k on the device, gather.  Returns (origins[k,3], dirs[k,3], pixels[k] | None, idx)."""
+    Efraimidis-Spirakis keys log(u)/w, radix-select top-k on the device (afx_topk_indices), gather.  Returns (origins[k,3], dirs[k,3], pixels[k] | None, idx)."""
     lib = _lib.load()
     dev = origins.device
     if dev.type != "cuda":
@@ -490,7 +508,7 @@ def sample_rays(origins, dirs, pixels, weights, k, u=None, seed=0, stream_id=0):
     keys = torch.empty(n, device=dev)
     st = Engine._stream(dev)
     _lib.check(lib.afx_sample_keys(_ptr(weights), n, _ptr(u), int(seed), int(stream_id), _ptr(keys), st), "afx_sample_keys")
-    idx = torch.topk(keys, int(k), sorted=True).indices      # (order of the top-k = a random order of the sample: keys are i.i.d.)
+    idx = topk_indices(keys, int(k))      # ascending table order: the batch is a set
     o, d = torch.empty(int(k), 3, device=dev), torch.empty(int(k), 3, device=dev)
     p = torch.empty(int(k), device=dev) if pixels is not None else None
     _lib.check(lib.afx_gather_rays(_ptr(origins), _ptr(dirs), _ptr(pixels), _ptr(idx), int(k), _ptr(o), _ptr(d), _ptr(p), st),

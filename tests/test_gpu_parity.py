@@ -1144,6 +1144,36 @@ def test_device_ray_sampler_and_philox():
     assert 0.005 < float(np.mean(frac_low)) < 0.05                          # expected share of the down-weighted half ~ 2 %
 
 
+def test_topk_radix_select():
+    """afx_topk_indices (selection step of the ray sampler): bit-exact set equality with a sort, ascending output, ties by lowest
+    index, -inf keys, k = n, tiny and ragged sizes, run-to-run determinism."""
+    from nerf_for_angiography_amd import engine as eng
+    g = torch.Generator().manual_seed(5)
+    for n, k in ((1, 1), (7, 3), (1023, 1000), (1024, 1), (1025, 513), (300001, 5625), (900000, 5625), (4096, 4096)):
+        keys = torch.log(torch.rand(n, generator=g).clamp(min=1e-7)) / (torch.rand(n, generator=g) + 0.05)
+        if n > 100:
+            keys[::97] = -float("inf")
+        kd = keys.to(DEV)
+        idx = eng.topk_indices(kd, k)
+        assert idx.dtype == torch.int64 and idx.shape == (k,)
+        ref = torch.sort(keys, descending=True, stable=True).indices[:k]
+        assert torch.equal(idx.cpu(), torch.sort(ref).values), (n, k)
+        assert torch.equal(idx, eng.topk_indices(kd, k))
+    # ties: 5 distinct values over 10 000 keys; the k-th largest value is cut in index order
+    keys = torch.randint(0, 5, (10000,), generator=g).float()
+    for k in (1, 1999, 2000, 2001, 7777, 10000):
+        idx = eng.topk_indices(keys.to(DEV), k).cpu()
+        ref = torch.sort(torch.sort(keys, descending=True, stable=True).indices[:k]).values
+        assert torch.equal(idx, ref), k
+    # mixed signs, zeros and denormals order like floats
+    keys = torch.tensor([0.0, -0.0, 1e-45, -1e-45, 3.5, -3.5, float("inf"), -float("inf"), 1.0, -1.0])
+    idx = eng.topk_indices(keys.to(DEV), 4).cpu().tolist()
+    assert idx == [2, 4, 6, 8]
+    assert eng.topk_indices(keys.to(DEV), 0).numel() == 0
+    with pytest.raises(ValueError):
+        eng.topk_indices(keys.to(DEV), 11)
+
+
 def test_stratified_depths_fused():
     """R4: (a) parity mode - the reference-captured stratified depths of fixture G3 fed through the fused kernel (dense
     convention, shared z) against the oracle; (b) perf mode - randomize_depth drawn IN the kernel from Philox equals the
