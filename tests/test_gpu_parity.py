@@ -449,6 +449,19 @@ def test_argument_validation():
     # empty batch
     out = render_rays(m, o[:0], o[:0], 32, 0.0, 1.0)
     assert out.rgb_map.shape == (0,)
+    # afx_set_encoding_grad: only the fourier encoding has trainable coefficients; params are required with a target
+    buf = torch.zeros(15, device=DEV)
+    with pytest.raises(AfxError):
+        with m.engine.encoding_grad(m.flat_params, buf):
+            pass
+    mb = make_model(4, 64, "barf", precision="f16")
+    with pytest.raises(AfxError):
+        with mb.engine.encoding_grad(mb.flat_params, buf):
+            pass
+    mf = make_model(4, 64, "fourier", precision="f16")
+    assert mf.engine.lib.afx_set_encoding_grad(mf.engine.h, None, buf.data_ptr()) != 0       # target without params
+    with mf.engine.encoding_grad(mf.flat_params, buf):
+        pass                                                                                   # accepted, and switched off again
 
 
 # ------------------------------------------------------------------------------------------------
