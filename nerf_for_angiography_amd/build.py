@@ -14,6 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 DEPS = ["afx_api.hip", "afx_kernels_f32.hip", "afx_kernels_bf16.hip", "afx_inst.h", "afx_inst_chain16.hip",
         "afx_internal.h", os.path.join("..", "..", "include", "afx.h")]
 VARIANTS = {"": [], "safe": ["-DAFX_SAFE_WAITS"],
+            "window": ["-DAFX_STASH_WINDOW"],     # measurement: stash stores into an L2-resident window (no HBM write stream; wrong results)
             "gaps": ["-DAFX_GAPS=1"],      # A/B: the 8-bit-stash backward kernel with the MFMA-gap schedule (slower)
             "stamp": ["-DAFX_STAMP", "-DAFX_SINGLE_TU"]}      # diagnostic: per-phase cycle stamps of the backward chain kernel (one translation unit)
 

@@ -130,7 +130,12 @@ __device__ __forceinline__ int fperm8(int p) {
 // 16-byte stash store, non-temporal: the stash is written once and read once by another kernel, so it must not
 // displace the weight slabs every workgroup re-streams from L2.  A/B in one process on the 512^2x128 step,
 // k_chain<bwd>: plain 116 ms, nt 99 ms, sc1 (write-through) 121 ms.
+#ifdef AFX_STASH_WINDOW      // measurement build only (build.py --variant=window): every stash store lands in one 1 MiB window that stays in L2,
+__device__ char g_stash_window[1 << 20];      // i.e. the same instruction stream without the HBM write stream (results are garbage)
+__device__ __forceinline__ void stash_store(char* p, u32x4 v) { *(u32x4*)(g_stash_window + ((uintptr_t)p & 0xFFFF0u)) = v; }
+#else
 __device__ __forceinline__ void stash_store(char* p, u32x4 v) { __builtin_nontemporal_store(v, (u32x4*)p); }
+#endif
 
 // Packed-bf16 epilogue helpers.  The bf16 sign bit is the int16 sign bit, so ReLU of two packed values is
 // one v_pk_max_i16, [h != 0] per half one v_pk_min_u16, and a per-half 0xffff/0 mask from bit q of each
