@@ -248,7 +248,7 @@ static BwdLayout bwd_layout(const afx_ctx* c, int prec, int64_t n_rays) {
   const size_t F = c->d.width, N = c->d.n_hidden;
   BwdLayout B;
   size_t fixed = rup64((size_t)n_rays * 4, 256);   // dod (rays mode only)
-  fixed += rup64((N + 1) * (size_t)kSplits * F * F * 4, 256);     // partial
+  fixed += rup64((N + 2) * (size_t)kSplits * F * F * 4, 256);     // partial (slot N+1: the fourier-coefficient contraction)
   fixed += rup64((N + 2) * (size_t)kSplits * (F + 4) * 4, 256);   // partial2
   if (prec != AFX_PREC_F32) fixed += rup64((size_t)kSmallBlocks * (F * 16 * nk0_of(c) + 2 * F + 4) * 4, 256);   // partial_s
   fixed += 256;                                                     // gmax words (f16 mode), one per stash buffer
@@ -496,23 +496,15 @@ static int launch_wgrad16_t(afx_ctx* c, const WgradArgs& w, const ReduceArgs& rd
       c->attr_done.insert((const void*)k_wgrad_bf16<F, H16>);
     }
     ProfScope ps(c, AFX_K_WGRAD, st);
-    hipLaunchKernelGGL((k_wgrad_bf16<F, H16>), dim3(w.n_splits, N), dim3(512), lds, st, w);
+    // + the first layer (encoded inputs) and the fourier-coefficient contraction as extra grid rows
+    hipLaunchKernelGGL((k_wgrad_bf16<F, H16>), dim3(w.n_splits, N + (w.enc16 ? 1 + (w.coef_cols > 0 ? 1 : 0) : 0)), dim3(512), lds, st, w);
   }
   if (w.small_groups) hipLaunchKernelGGL(k_small_from_groups<F>, dim3(rd.n_small), dim3(F), 0, st, w);
-  else if (c->d.enc != AFX_ENC_NONE) hipLaunchKernelGGL((k_small_grads_bf16<F, true, H16>), dim3(rd.n_small, F / 64 * 4), dim3(256), 0, st, w);
-  else hipLaunchKernelGGL((k_small_grads_bf16<F, false, H16>), dim3(rd.n_small, F / 64), dim3(256), 0, st, w);
+  else hipLaunchKernelGGL((k_small_grads_bf16<F, H16>), dim3(rd.n_small, F / 64), dim3(256), 0, st, w);
   hipLaunchKernelGGL(k_reduce_w<F>, dim3((F * F + 255) / 256, N + 1), dim3(256), 0, st, rd);
   hipLaunchKernelGGL(k_reduce_b<F>, dim3(1, N + 2), dim3(F), 0, st, rd);
   hipLaunchKernelGGL(k_reduce_small<F>, dim3((unsigned)((F * rd.k0pad + 2 * F + 1 + 63) / 64)), dim3(64, 4), 0, st, rd);
-  if (c->d_coef && c->d.enc == AFX_ENC_FOURIER) {
-    // second pass over dZ_0 and the encoded inputs, against d(enc)/d(coef); the records of the first pass are reduced by now
-    WgradArgs w2 = w;
-    ReduceArgs r2 = rd;
-    w2.coef_cols = r2.coef_cols = 3 * c->d.n_freq;
-    r2.w0 = c->coef_params; r2.d_coef = c->d_coef;
-    hipLaunchKernelGGL((k_small_grads_bf16<F, true, H16>), dim3(rd.n_small, F / 64 * 4), dim3(256), 0, st, w2);
-    hipLaunchKernelGGL(k_reduce_coef<F>, dim3(r2.coef_cols), dim3(F), 0, st, r2);
-  }
+  if (w.coef_cols > 0) hipLaunchKernelGGL(k_reduce_coef<F>, dim3(rd.coef_cols), dim3(F), 0, st, rd);
   HIPCHK(hipGetLastError());
   return AFX_OK;
 }
@@ -573,7 +565,7 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
     chunk /= 2;
   }
   size_t off = head;
-  float* partial = (float*)(ws + off); off += rup64((size_t)(N + 1) * kSplits * F * F * 4, 256);
+  float* partial = (float*)(ws + off); off += rup64((size_t)(N + 2) * kSplits * F * F * 4, 256);
   float* partial2 = (float*)(ws + off); off += rup64((size_t)(N + 2) * kSplits * (F + 4) * 4, 256);
   float* partial_s = (float*)(ws + off);
   if (b16) off += rup64((size_t)kSmallBlocks * (F * k0ld + 2 * F + 4) * 4, 256);
@@ -589,6 +581,10 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
   }
   a.stash_rows = (int64_t)rows;
   a.debug = 0;
+  // encoded inputs, 16-bit kernels: the inputs are stashed in 16-bit chunk-major form and the first layer's weight gradient (and the
+  // fourier coefficients' gradient, afx_set_encoding_grad) is contracted on the matrix pipe by k_wgrad_bf16
+  const bool enc16 = b16 && c->d.enc != AFX_ENC_NONE;
+  a.coef_cols = (enc16 && c->d_coef && c->d.enc == AFX_ENC_FOURIER) ? 3 * c->d.n_freq : 0;
   // in-kernel small gradients: 8-wave bf16 backward kernel, rays, raw coordinates as inputs (AFX_SMALL_IN_KERNEL=0: off)
   a.stash8 = s8 ? 1 : 0;
   a.persistent = (nbuf == 2 && !c->persistent_chain) ? 0 : 1;
@@ -626,12 +622,13 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
     rps = (rps + 63) / 64 * 64;        // whole 32-/64-sample stages
     w.rows_per_split = (int)rps;
     w.partial = partial; w.partial2 = partial2; w.partial_s = partial_s; w.debug = a.debug; w.small_groups = sg ? 1 : 0;
-    w.gmax = a.gmax; w.stash_esz = (int)esz; w.gexp = a.gexp; w.coef_cols = 0;
+    w.gmax = a.gmax; w.stash_esz = (int)esz; w.gexp = a.gexp; w.enc16 = enc16 ? 1 : 0; w.coef_cols = a.coef_cols;
     ReduceArgs rd;
     rd.partial = partial; rd.partial2 = partial2; rd.n_hidden = N; rd.k0 = c->k0; rd.k0pad = k0ld; rd.n_splits = splits;
     rd.grad = grad_flat; rd.hidden_only = b16 ? 1 : 0; rd.partial_s = partial_s;
     rd.n_small = kSmallBlocks;      // records; every record is written (possibly with zero rows)
-    rd.gmax = a.gmax; rd.scale_shift = s8 ? AFX_S8_JSHIFT : 0; rd.w0 = nullptr; rd.d_coef = nullptr; rd.coef_cols = 0;
+    rd.gmax = a.gmax; rd.scale_shift = s8 ? AFX_S8_JSHIFT : 0; rd.layer0_mfma = enc16 ? 1 : 0;
+    rd.w0 = c->coef_params; rd.d_coef = c->d_coef; rd.coef_cols = a.coef_cols;
     if (!b16) rc = F == 64 ? launch_wgrad_t<64>(c, w, rd, N, ws_st) : (F == 128 ? launch_wgrad_t<128>(c, w, rd, N, ws_st) : launch_wgrad_t<256>(c, w, rd, N, ws_st));
     else if (s8) rc = F == 64 ? launch_wgrad8_t<64>(c, w, rd, N, ws_st) : (F == 128 ? launch_wgrad8_t<128>(c, w, rd, N, ws_st) : launch_wgrad8_t<256>(c, w, rd, N, ws_st));
     else if (h16) rc = F == 64 ? launch_wgrad16_t<64, true>(c, w, rd, N, ws_st) : (F == 128 ? launch_wgrad16_t<128, true>(c, w, rd, N, ws_st) : launch_wgrad16_t<256, true>(c, w, rd, N, ws_st));

@@ -64,7 +64,9 @@ struct ChainArgs {
   const float* dod;         // [R] dL/d(optical depth)
   float* stash_h;           // [(N+1), rows, F]   post-activation H_0..H_N
   float* stash_dz;          // [(N+1), rows, F]   dL/dZ_0..dZ_N
-  float* stash_e;           // [rows, 2*nq]       encoded inputs
+  float* stash_e;           // f32 kernels / raw-coordinate inputs: [rows, 2*nq] fp32 encoded inputs.  16-bit kernels WITH an encoding: 16-bit
+                            // chunk-major stash [row>>5][8 chunks][row&31][8 values] of the 64 input columns, and behind it (stash_rows*128 B)
+                            // the same layout of d(enc)/d(coef)/(2 pi) when coef_cols > 0
   float* graw;              // [rows]             dL/draw
   int64_t stash_rows;
   int32_t persistent;       // 1: grid = #CUs, workgroups loop over tiles; 0: one workgroup per tile (lets the dispatcher
@@ -79,6 +81,7 @@ struct ChainArgs {
   uint32_t* gmax;           // f16 mode: bit pattern of max |dL/draw| over the chunk (integer atomicMax; zeroed per chunk)
   int32_t stash8;           // f16 mode: 8-bit (bf8) stash of H_l and dZ'_l
   int32_t* gexp;            // 8-bit stash: power-of-two exponent of each 32-sample group's largest |dL/draw| [rows/32]
+  int32_t coef_cols;        // 3*n_freq when the fourier coefficients train (the chain kernel then also stashes d(enc)/d(coef)/(2 pi)), else 0
 };
 
 struct WgradArgs {
@@ -90,7 +93,7 @@ struct WgradArgs {
   int64_t stride_rows;      // layer stride of the stash (rows of a full chunk)
   int32_t n_hidden, k0, k0pad;
   int32_t n_splits, rows_per_split;   // rows_per_split even
-  float* partial;           // [(N+1), n_splits, F*F]
+  float* partial;           // [(N+2), n_splits, F*F]: slot l = layer l; slot N+1 = the d(enc)/d(coef) contraction
   float* partial2;          // [(N+2), n_splits, F+4]
   int32_t debug;            // timing experiments only (bit5: default-policy instead of non-temporal stash loads)
   float* partial_s;         // bf16 path: [n_small, F*k0pad + 2F + 4] first-layer / output-layer partials
@@ -98,7 +101,9 @@ struct WgradArgs {
   const uint32_t* gmax;     // f16 mode: the chunk's max |dL/draw| (scale of the contraction, wgrad_scale_exp)
   int32_t stash_esz;        // bytes per stash element (4 f32, 2 bf16/f16, 1 bf8)
   const int32_t* gexp;      // 8-bit stash: group exponents (block scales of the MX contraction)
-  int32_t coef_cols;        // k_small_grads_bf16, fourier encoding: > 0 = contract dZ_0 with d(enc)/d(coef) columns instead of enc (3*n_freq)
+  int32_t enc16;            // 16-bit kernels with an encoding: stash_e is the 16-bit chunk-major input stash; k_wgrad_bf16 contracts layer 0 on
+                            // the matrix pipe (blockIdx.y = n_hidden) and, with coef_cols > 0, d(enc)/d(coef) as well (blockIdx.y = n_hidden + 1)
+  int32_t coef_cols;        // 3*n_freq when the fourier coefficients train, else 0
 };
 
 struct ReduceArgs {
@@ -106,6 +111,7 @@ struct ReduceArgs {
   const float* partial2;
   int32_t n_hidden, k0, k0pad, n_splits;
   int32_t hidden_only;      // bf16 path: layer 0 and the output layer are reduced by k_reduce_small
+  int32_t layer0_mfma;      // ... unless layer 0 came out of k_wgrad_bf16 (enc16): then k_reduce_w / k_reduce_b take it like a hidden layer
   int32_t n_small;
   const float* partial_s;
   float* grad;              // flat parameter gradient, accumulated into

@@ -368,9 +368,22 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
         }
         split_frag(e, ehi[cg][q], elo[cg][q]);
         if (BWD && !SG) {
-          float* ep = a.stash_e + (size_t)m[cg] * (16 * NK0) + 16 * q + 8 * hh;
-          *(f32x4*)ep = (f32x4){e[0], e[1], e[2], e[3]};
-          *(f32x4*)(ep + 4) = (f32x4){e[4], e[5], e[6], e[7]};
+          if constexpr (ENC) {
+            // 16-bit chunk-major stash of the encoded inputs (the B operand of the first layer's weight gradient in k_wgrad_bf16):
+            // this lane's 8 values are input columns 16q + 8hh .. +7 of its sample = chunk 2q + hh of the row, natural order
+            char* ep = (char*)a.stash_e + ((((size_t)(m[cg] >> 5) * 8 + (2 * q + hh)) << 5) + (m[cg] & 31)) * 16;
+            stash_store(ep, (u32x4){pack2t<H16>(e[0], e[1]), pack2t<H16>(e[2], e[3]), pack2t<H16>(e[4], e[5]), pack2t<H16>(e[6], e[7])});
+            if (a.coef_cols > 0) {       // trainable fourier coefficients: the same for d(enc)/d(coef)/(2 pi)
+              float de[8];
+#pragma unroll
+              for (int j = 0; j < 8; ++j) de[j] = enc_dcoef(16 * q + 8 * hh + j, sp[cg].px, sp[cg].py, sp[cg].pz, aux, a.n_freq);
+              stash_store(ep + (size_t)a.stash_rows * 128, (u32x4){pack2t<H16>(de[0], de[1]), pack2t<H16>(de[2], de[3]), pack2t<H16>(de[4], de[5]), pack2t<H16>(de[6], de[7])});
+            }
+          } else {
+            float* ep = a.stash_e + (size_t)m[cg] * (16 * NK0) + 16 * q + 8 * hh;
+            *(f32x4*)ep = (f32x4){e[0], e[1], e[2], e[3]};
+            *(f32x4*)(ep + 4) = (f32x4){e[4], e[5], e[6], e[7]};
+          }
         }
       }
     }
@@ -953,17 +966,24 @@ __global__ void __launch_bounds__(512) k_wgrad_bf16(const WgradArgs a) {
   // provably wave-uniform: `if (i == wc)` around an MFMA must be a SCALAR branch - MFMA ignores EXEC, so under an
   // exec-masked "branch" all four candidates would execute
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int layer = blockIdx.y + 1, split = blockIdx.x;
+  // blockIdx.y < N: hidden layer blockIdx.y + 1.  enc16 (encoded inputs): blockIdx.y = N is the FIRST layer - A = dZ_0, B = the 16-bit
+  // stash of the 64 input columns (8 chunk columns, natural column order) - and blockIdx.y = N + 1 contracts dZ_0 with
+  // d(enc)/d(coef) for the fourier coefficients (k_reduce_coef); both use the two left-most column tiles only.
+  const int first = (int)blockIdx.y - a.n_hidden;           // < 0: hidden layer
+  const int layer = first < 0 ? (int)blockIdx.y + 1 : 0, split = blockIdx.x;
+  const int slot = first <= 0 ? layer : a.n_hidden + 1;     // partial slot
+  const int nchb = first < 0 ? NCH : 8;
   float ls = 1.f;
   if constexpr (H16) ls = ldexpf(1.f, -wgrad_scale_exp(a.gmax));
   const char* A = (const char*)a.stash_dz + (size_t)layer * a.stride_rows * RB;
-  const char* B = (const char*)a.stash_h + (size_t)(layer - 1) * a.stride_rows * RB;
+  const char* B = first < 0 ? (const char*)a.stash_h + (size_t)(layer - 1) * a.stride_rows * RB
+                            : (const char*)a.stash_e + (size_t)first * a.stride_rows * 128;
   int64_t r0 = (int64_t)split * a.rows_per_split;
   int64_t r1 = r0 + a.rows_per_split;
   if (r1 > a.rows) r1 = a.rows;
   const int nst = r1 > r0 ? (int)((r1 - r0) / KB) : 0;
-  const bool active = wave < WR * WC;
   const int wr = wave / WC, wc = wave % WC;
+  const bool active = wave < WR * WC;      // (first layer: only column tiles 0, 1 of B exist; the other waves' products are never stored)
 
   f32x16 acc[TR][TC];
 #pragma unroll
@@ -980,7 +1000,11 @@ __global__ void __launch_bounds__(512) k_wgrad_bf16(const WgradArgs a) {
       const size_t src = ((((size_t)(g0 + hh) * NCH + c) << 5) + col) << 4;
       // default cache policy: non-temporal loads (aux = 2) measured 2 ms slower per step here
       __builtin_amdgcn_global_load_lds(GPTR(A + src), LPTR(dA + c * CS), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(GPTR(B + src), LPTR(dB + c * CS), 16, 0, 0);
+      if (first < 0) __builtin_amdgcn_global_load_lds(GPTR(B + src), LPTR(dB + c * CS), 16, 0, 0);
+    }
+    if (first >= 0) {       // 8 chunk columns of the input stash: one per wave
+      const size_t src = ((((size_t)(g0 + hh) * 8 + wave) << 5) + col) << 4;
+      __builtin_amdgcn_global_load_lds(GPTR(B + src), LPTR(dB + wave * CS), 16, 0, 0);
     }
   };
   // transpose-read (ds_read_b64_tr_b16): lane 4q+p of each 16-lane group supplies the address of stage row
@@ -1049,8 +1073,8 @@ __global__ void __launch_bounds__(512) k_wgrad_bf16(const WgradArgs a) {
       }
     }
   }
-  float* P = a.partial + ((size_t)layer * a.n_splits + split) * F * F;
-  if (active) {
+  float* P = a.partial + ((size_t)slot * a.n_splits + split) * F * F;
+  if (active && first < 0) {
 #pragma unroll
     for (int i = 0; i < TR; ++i)
 #pragma unroll
@@ -1058,8 +1082,18 @@ __global__ void __launch_bounds__(512) k_wgrad_bf16(const WgradArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           P[(size_t)fperm(32 * (wr * TR + i) + rowperm(r) + 4 * hh) * F + fperm(32 * (wc * TC + j) + col)] = acc[i][j][r];
+  } else if (active) {      // first layer: rows [F] x k0pad = 64 input columns in natural order (the layout k_reduce_w expects)
+#pragma unroll
+    for (int i = 0; i < TR; ++i)
+#pragma unroll
+      for (int j = 0; j < TC; ++j)
+        if (wc * TC + j < 2) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            P[(size_t)fperm(32 * (wr * TR + i) + rowperm(r) + 4 * hh) * a.k0pad + 32 * (wc * TC + j) + col] = acc[i][j][r];
+        }
   }
-  if (has_bias && col == 0) {        // every column of accb holds the row sums
+  if (has_bias && col == 0 && first <= 0) {        // every column of accb holds the row sums
 #pragma unroll
     for (int r = 0; r < 16; ++r)
       a.partial2[((size_t)layer * a.n_splits + split) * (F + 4) + fperm(32 * (wr * TR + wc) + rowperm(r) + 4 * hh)] = accb[r];
@@ -1215,28 +1249,27 @@ __global__ void __launch_bounds__(512) k_wgrad_s8(const WgradArgs a) {
   }
 }
 
-// First-layer weight gradient (dW_0 = dZ_0^T E, K0 columns, fp32 on the VALU), its bias, and the output
-// layer (dw_out = sum_n g_n H_N[n], db_out = sum_n g_n) from the bf16 stashes: one pass over dZ_0, H_N, E, g.
-// grid = n_small blocks, block = F threads (thread p = stash position; feature = fperm(p)).
-// Block b writes its partial record of SS = F*k0pad + 2F + 4 floats; k_reduce_small sums the records in order.
-
-// grid = (n_records, F/64 * (ENC ? 4 : 1)), block = 256 = 8 chunk columns x 32 rows: a wave reads two contiguous
-// 512-byte runs of the chunk-major stash.  blockIdx.y selects 64 stash positions (and, with an encoding, which
-// 2 of each chunk's 8 positions this block accumulates, to bound the accumulator count).
-template <int F, bool ENC, bool H16 = false>
+// First-layer weight gradient for RAW-coordinate inputs (dW_0 = dZ_0^T x, 3 columns, fp32 on the VALU), its bias, and the output
+// layer (dw_out = sum_n g_n H_N[n], db_out = sum_n g_n) from the 16-bit stashes: one pass over dZ_0, H_N, x, g.  With an
+// encoding (a.enc16) the first layer's weights and bias come out of k_wgrad_bf16 (64 input columns on the matrix pipe;
+// this VALU kernel took 74 % of a BARF training iteration when it did them) and only the output layer is summed here.
+// grid = (n_records, F/64), block = 256 = 8 chunk columns x 32 rows: a wave reads two contiguous 512-byte runs of the
+// chunk-major stash; blockIdx.y selects 64 stash positions.  Block b writes its partial record of
+// SS = F*k0pad + 2F + 4 floats; k_reduce_small sums the records in order.
+template <int F, bool H16 = false>
 __global__ void __launch_bounds__(256) k_small_grads_bf16(const WgradArgs a) {
-  constexpr int KMAX = ENC ? 64 : 4;
-  constexpr int PPT = ENC ? 2 : 8;
+  constexpr int KMAX = 4;
+  constexpr int PPT = 8;
   constexpr int NCH = F / 8;
   const int cq = threadIdx.x >> 5, rr = threadIdx.x & 31;
-  const int ygrp = ENC ? blockIdx.y >> 2 : blockIdx.y, sub = ENC ? (blockIdx.y & 3) : 0;
-  const int ch = ygrp * 8 + cq;                               // chunk column of this thread
+  const int ch = blockIdx.y * 8 + cq;                         // chunk column of this thread
   const int64_t ngroups = a.rows >> 5;
   const int64_t per = (ngroups + gridDim.x - 1) / gridDim.x;
   int64_t g0 = (int64_t)blockIdx.x * per, g1 = g0 + per;
   if (g1 > ngroups) g1 = ngroups;
   const char* dz0 = (const char*)a.stash_dz;
   const char* hN = (const char*)a.stash_h + (size_t)a.n_hidden * a.stride_rows * F * 2;
+  const bool raw_inputs = !a.enc16;
   float acc[PPT][KMAX], bs[PPT], so[PPT];
 #pragma unroll
   for (int i = 0; i < PPT; ++i) {
@@ -1252,30 +1285,16 @@ __global__ void __launch_bounds__(256) k_small_grads_bf16(const WgradArgs a) {
     const int64_t r = (g << 5) + rr;
     const float gr = a.graw[r];
     sg += gr;
-    const float* e = a.stash_e + r * a.k0pad;
     float ev[KMAX];
 #pragma unroll
-    for (int c = 0; c < KMAX; ++c) ev[c] = c < a.k0 ? e[c] : 0.f;
-    if (ENC && a.coef_cols > 0) {
-      // fourier_pos_enc (model/CPPN.py:320-327): enc = [x | sin(2 pi x_c coef_m) | cos(2 pi x_c coef_m)], c = m % 3, so
-      // d enc[3+m]/d coef_m = 2 pi x_c cos(.) = 2 pi enc[c] enc[3+nb+m] and d enc[3+nb+m]/d coef_m = -2 pi enc[c] enc[3+m]:
-      // column m (m+nb) of this pass accumulates G[f][m] = sum_n dZ_0[n][f] * that derivative; k_reduce_coef contracts G with W_0.
-      const int nb = a.coef_cols;
-#pragma unroll
-      for (int c = 0; c < KMAX; ++c) {
-        const bool second = c >= nb;
-        const int m = second ? c - nb : c;
-        ev[c] = c < 2 * nb ? (second ? -6.283185307179586f : 6.283185307179586f) * e[m % 3] * e[min(second ? 3 + m : 3 + nb + m, a.k0 - 1)] : 0.f;
-      }
-    }
+    for (int c = 0; c < KMAX; ++c) ev[c] = (raw_inputs && c < a.k0) ? a.stash_e[r * a.k0pad + c] : 0.f;
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
-      const int e8 = ENC ? 2 * sub + i : i;                   // element of the 16-byte chunk
-      const unsigned dw = e8 < 2 ? x[0] : (e8 < 4 ? x[1] : (e8 < 6 ? x[2] : x[3]));
-      const unsigned hw = e8 < 2 ? y[0] : (e8 < 4 ? y[1] : (e8 < 6 ? y[2] : y[3]));
+      const unsigned dw = i < 2 ? x[0] : (i < 4 ? x[1] : (i < 6 ? x[2] : x[3]));
+      const unsigned hw = i < 2 ? y[0] : (i < 4 ? y[1] : (i < 6 ? y[2] : y[3]));
       // H16: the stash holds J_0 = dZ_0 / g
-      const float d = ((e8 & 1) ? hi_t<H16>(dw) : lo_t<H16>(dw)) * (H16 ? gr : 1.f);
-      const float h = (e8 & 1) ? hi_t<H16>(hw) : lo_t<H16>(hw);
+      const float d = ((i & 1) ? hi_t<H16>(dw) : lo_t<H16>(dw)) * (H16 ? gr : 1.f);
+      const float h = (i & 1) ? hi_t<H16>(hw) : lo_t<H16>(hw);
       bs[i] += d;
       so[i] = fmaf(gr, h, so[i]);
 #pragma unroll
@@ -1292,11 +1311,11 @@ __global__ void __launch_bounds__(256) k_small_grads_bf16(const WgradArgs a) {
   float* P = a.partial_s + (size_t)blockIdx.x * SS;
 #pragma unroll
   for (int i = 0; i < PPT; ++i) {
-    const int f = fperm(ch * 8 + (ENC ? 2 * sub + i : i));
+    const int f = fperm(ch * 8 + i);
 #pragma unroll
     for (int c = 0; c < KMAX; ++c) {
       const float v = red32(acc[i][c]);
-      if (rr == 0 && c < a.k0) P[(size_t)f * a.k0pad + c] = v;
+      if (rr == 0 && raw_inputs && c < a.k0) P[(size_t)f * a.k0pad + c] = v;
     }
     const float vb = red32(bs[i]), vo = red32(so[i]);
     if (rr == 0) { P[(size_t)F * a.k0pad + f] = vb; P[(size_t)F * a.k0pad + F + f] = vo; }
@@ -1360,6 +1379,7 @@ __global__ void __launch_bounds__(256) k_reduce_small(const ReduceArgs a) {
   red[grp][threadIdx.x] = s;
   __syncthreads();
   if (grp != 0 || !valid) return;
+  if (a.layer0_mfma && e < (size_t)F * a.k0pad + F) return;      // first layer: reduced by k_reduce_w / k_reduce_b from k_wgrad_bf16's partials
   s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
   const size_t wout = (size_t)F * a.k0 + F + (size_t)a.n_hidden * ((size_t)F * F + F);
   size_t dst;
@@ -1372,21 +1392,22 @@ __global__ void __launch_bounds__(256) k_reduce_small(const ReduceArgs a) {
   a.grad[dst] += s;
 }
 
-// Fourier coefficients' gradient from the records of a coef_cols pass of k_small_grads_bf16:
-// d_coef[m] += sum_f W_0[f][3+m] G[f][m] + W_0[f][3+nb+m] G[f][nb+m].  grid = nb blocks of F threads; fixed summation order.
+// Fourier coefficients' gradient from k_wgrad_bf16's coefficient pass (slot N+1 of `partial`: G[f][c] = sum_n dZ_0[n][f] D[n][c], D =
+// d(enc)/d(coef)/(2 pi), carrying the same power-of-two scale as the hidden layers in f16 mode):
+//   d_coef[m] += 2 pi * sum_f ( W_0[f][3+m] G[f][m] + W_0[f][3+nb+m] G[f][nb+m] ).   grid = nb blocks of F threads; fixed order.
 template <int F>
 __global__ void __launch_bounds__(F) k_reduce_coef(const ReduceArgs a) {
   __shared__ float red[F];
   const int m = blockIdx.x, f = threadIdx.x, nb = a.coef_cols;
-  const size_t SS = (size_t)F * a.k0pad + 2 * F + 4;
   float g1 = 0.f, g2 = 0.f;
-#pragma unroll 4
-  for (int b = 0; b < a.n_small; ++b) {
-    const float* P = a.partial_s + (size_t)b * SS + (size_t)f * a.k0pad;
+  for (int sp = 0; sp < a.n_splits; ++sp) {
+    const float* P = a.partial + ((size_t)(a.n_hidden + 1) * a.n_splits + sp) * F * F + (size_t)f * a.k0pad;
     g1 += P[m];
     g2 += P[nb + m];
   }
-  red[f] = fmaf(a.w0[(size_t)f * a.k0 + 3 + m], g1, a.w0[(size_t)f * a.k0 + 3 + nb + m] * g2);
+  float v = fmaf(a.w0[(size_t)f * a.k0 + 3 + m], g1, a.w0[(size_t)f * a.k0 + 3 + nb + m] * g2) * 6.283185307179586f;
+  if (a.gmax) v *= ldexpf(1.f, wgrad_scale_exp(a.gmax) - a.scale_shift);
+  red[f] = v;
   __syncthreads();
   for (int s = F / 2; s >= 1; s >>= 1) {
     if (f < s) red[f] += red[f + s];

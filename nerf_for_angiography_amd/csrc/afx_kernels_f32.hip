@@ -64,6 +64,20 @@ __device__ __forceinline__ float enc_value(int k, float px, float py, float pz, 
   return is_cos ? cosf(v) : sinf(v);
 }
 
+// d(enc)/d(coef) / (2 pi) of the fourier encoding (fourier_pos_enc, model/CPPN.py:320-327), as 2*nb extra "input columns":
+// column m < nb: d enc[3+m] / d coef_m = 2 pi x_c cos(v);  column nb+m: d enc[3+nb+m] / d coef_m = -2 pi x_c sin(v)  (c = m % 3).
+// The factor 2 pi is applied by k_reduce_coef (keeps the f16 stash of x cos(v) inside f16's range for |x| < 65 504).
+__device__ __forceinline__ float enc_dcoef(int k, float px, float py, float pz, const float* aux, int n_freq) {
+  const int nb = 3 * n_freq;
+  if (k >= 2 * nb) return 0.f;
+  const bool second = k >= nb;
+  const int m = second ? k - nb : k;
+  const int c = m % 3;
+  const float x = c == 0 ? px : (c == 1 ? py : pz);
+  const float v = __fmul_rn(__fmul_rn(6.283185307179586f, x), aux[m]);
+  return second ? -x * sinf(v) : x * cosf(v);
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
 // Per-lane description of the sample a lane's column holds.
@@ -561,7 +575,7 @@ __global__ void __launch_bounds__(1024) k_colsum_f32(const WgradArgs a) {
 template <int F>
 __global__ void k_reduce_w(const ReduceArgs a) {
   const int layer = blockIdx.y;
-  if (a.hidden_only && layer == 0) return;
+  if (a.hidden_only && layer == 0 && !a.layer0_mfma) return;
   const int ncols = layer == 0 ? a.k0pad : F;
   const int ncr = layer == 0 ? a.k0 : F;
   const int e = blockIdx.x * 256 + threadIdx.x;
@@ -580,7 +594,7 @@ __global__ void k_reduce_w(const ReduceArgs a) {
 template <int F>
 __global__ void k_reduce_b(const ReduceArgs a) {
   const int y = blockIdx.y, f = threadIdx.x;
-  if (a.hidden_only && (y == 0 || y == a.n_hidden + 1)) return;
+  if (a.hidden_only && ((y == 0 && !a.layer0_mfma) || y == a.n_hidden + 1)) return;
   float s = 0.f, sg = 0.f;
   for (int sp = 0; sp < a.n_splits; ++sp) {
     const float* P = a.partial2 + ((size_t)y * a.n_splits + sp) * (F + 4);

@@ -18,9 +18,11 @@ tab_o = torch.randn(NT, 3, device=dev) * 3 + torch.tensor([0, 0, 1500.0], device
 tab_d = torch.nn.functional.normalize(torch.randn(NT, 3, device=dev) * 0.03 + torch.tensor([0, 0, -1.0], device=dev), dim=-1)
 tab_p, tab_w = torch.rand(NT, device=dev), torch.rand(NT, device=dev) + 0.05
 md = dict(num_early_layers=layers, num_late_layers=0, num_filters=width, num_input_channels=3, num_output_channels=1,
-          num_input_channels_views=0, use_bias=True, pos_enc="none", pos_enc_basis=5, act_func="relu", fourier_sigma=5,
+          num_input_channels_views=0, use_bias=True, pos_enc=os.environ.get("ENC", "none"), pos_enc_basis=5, act_func="relu", fourier_sigma=5,
           num_img=1, device=dev, precision=os.environ.get("PREC", "f16s8"))
 m = CPPN(md).to(dev)
+if md["pos_enc"] == "barf":
+    m.update_barf_alpha(2.5, "pts")
 opt = torch.optim.Adam(m.parameters(), lr=1e-4)
 R, S = 5625, 300
 n = [0]
