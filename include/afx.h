@@ -54,8 +54,9 @@ enum { AFX_ENC_NONE = 0, AFX_ENC_BARF = 1, AFX_ENC_FOURIER = 2 };
  *            results are identical to F16; weight gradients carry the extra
  *            bf8 rounding of the two contraction operands (~5e-3 relative L2 at
  *            262 144 samples, below BF16's ~1e-2; the rounding is zero-mean and
- *            averages out over samples).  Rays mode without an encoding; other
- *            configurations run exactly as F16.                                */
+ *            averages out over samples).  Rays mode (with an input encoding
+ *            the encoded inputs are stashed as bf8 as well); points mode
+ *            (afx_mlp_backward) runs exactly as F16.                           */
 enum { AFX_PREC_F32 = 0, AFX_PREC_BF16X3 = 1, AFX_PREC_BF16 = 2, AFX_PREC_F16 = 3, AFX_PREC_F16S8 = 4 };
 
 /* CPPN(model_definition) — model/CPPN.py:10-139.  Only the configuration

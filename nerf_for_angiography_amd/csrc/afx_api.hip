@@ -347,7 +347,9 @@ static int launch_chain_f(afx_ctx* c, int prec, bool bwd, const ChainArgs& a, si
     return enc ? launch_chain_k(c, k_chain_bf16<F, true, true, false, 4>, which, a, lds, grid, st)
                : launch_chain_k(c, k_chain_bf16<F, true, false, false, 4>, which, a, lds, grid, st);
   if (is_f16(prec)) {
-    if (bwd && a.small_part && a.stash8) return launch_chain_k(c, k_chain_bf16<F, false, false, true, 8, true, true, true>, which, a, lds, grid, st, 512);
+    if (bwd && a.small_part && a.stash8)
+      return enc ? launch_chain_k(c, k_chain_bf16<F, false, true, true, 8, true, true, true>, which, a, lds, grid, st, 512)
+                 : launch_chain_k(c, k_chain_bf16<F, false, false, true, 8, true, true, true>, which, a, lds, grid, st, 512);
     if (bwd && a.small_part) return launch_chain_k(c, k_chain_bf16<F, false, false, true, 8, true, true>, which, a, lds, grid, st, 512);
     if (bwd)
       return enc ? launch_chain_k(c, k_chain_bf16<F, false, true, true, 8, false, true>, which, a, lds, grid, st, 512)
@@ -519,12 +521,13 @@ static int launch_wgrad8_t(afx_ctx* c, const WgradArgs& w, const ReduceArgs& rd,
       c->attr_done.insert((const void*)k_wgrad_s8<F>);
     }
     ProfScope ps(c, AFX_K_WGRAD, st);
-    hipLaunchKernelGGL(k_wgrad_s8<F>, dim3(w.n_splits, N), dim3(512), lds, st, w);
+    hipLaunchKernelGGL(k_wgrad_s8<F>, dim3(w.n_splits, N + (w.enc16 ? 1 + (w.coef_cols > 0 ? 1 : 0) : 0)), dim3(512), lds, st, w);
   }
   hipLaunchKernelGGL(k_small_from_groups<F>, dim3(rd.n_small), dim3(F), 0, st, w);
   hipLaunchKernelGGL(k_reduce_w<F>, dim3((F * F + 255) / 256, N + 1), dim3(256), 0, st, rd);
   hipLaunchKernelGGL(k_reduce_b<F>, dim3(1, N + 2), dim3(F), 0, st, rd);
   hipLaunchKernelGGL(k_reduce_small<F>, dim3((unsigned)((F * rd.k0pad + 2 * F + 1 + 63) / 64)), dim3(64, 4), 0, st, rd);
+  if (w.coef_cols > 0) hipLaunchKernelGGL(k_reduce_coef<F>, dim3(rd.coef_cols), dim3(F), 0, st, rd);
   HIPCHK(hipGetLastError());
   return AFX_OK;
 }
@@ -541,11 +544,12 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
   if (c->d_coef && c->d.enc == AFX_ENC_FOURIER && !b16)
     return fail(AFX_E_INVALID, "backward: the fourier coefficients' gradient (afx_set_encoding_grad) needs a 16-bit precision");
   // in-kernel small gradients: 8-wave 16-bit backward kernel, rays, raw coordinates as inputs (AFX_SMALL_IN_KERNEL=0: off)
-  const bool sg = b16 && a.mode == 1 && c->d.enc == AFX_ENC_NONE && c->small_in_kernel;
+  // (with an input encoding only the 8-bit-stash kernel has the in-kernel output-layer sums; its first layer goes through k_wgrad_s8)
+  const bool sg = b16 && a.mode == 1 && c->small_in_kernel && (c->d.enc == AFX_ENC_NONE || prec == AFX_PREC_F16S8);
   const bool s8 = prec == AFX_PREC_F16S8 && sg;          // 8-bit stash: that configuration only; otherwise the 16-bit f16 path
   const size_t esz = s8 ? 1 : (b16 ? 2 : 4);            // stash element size
   const int k0ld = b16 ? 16 * nk0_of(c) : c->k0pad;     // row length of the encoded-input stash
-  if (is_bf16(prec) && prec == AFX_PREC_F16S8 && a.mode == 1 && c->d.enc == AFX_ENC_NONE && c->small_in_kernel)
+  if (is_bf16(prec) && prec == AFX_PREC_F16S8 && a.mode == 1 && c->small_in_kernel)
     B.per_tile_bytes = (size_t)256 * (2 * ((size_t)c->d.n_hidden + 1) * c->d.width + 4 * 16 * nk0_of(c) + 4);     // 1 byte per stash element
   if (ws_bytes < fixed + B.per_tile_bytes + 1024) return fail(AFX_E_WORKSPACE, "backward workspace %zu too small (min %zu)", ws_bytes, fixed + 32 * B.per_tile_bytes);
   const int64_t tiles = (a.n_total + TILE - 1) / TILE;

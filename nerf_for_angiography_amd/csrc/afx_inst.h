@@ -16,7 +16,8 @@
   X(F, false, false, true, 8, false, true, false)   \
   X(F, false, true, true, 8, false, true, false)    \
   X(F, false, false, true, 8, true, true, false)    \
-  X(F, false, false, true, 8, true, true, true)
+  X(F, false, false, true, 8, true, true, true)    \
+  X(F, false, true, true, 8, true, true, true)
 #define AFX_CHAIN16_DECL(F, X3, ENC, BWD, NW, SG, H16, S8) \
   extern template __global__ void k_chain_bf16<F, X3, ENC, BWD, NW, SG, H16, S8>(const afx::ChainArgs);
 #define AFX_CHAIN16_DEF(F, X3, ENC, BWD, NW, SG, H16, S8) \

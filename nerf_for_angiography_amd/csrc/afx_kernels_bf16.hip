@@ -98,6 +98,15 @@ __device__ __forceinline__ u32x4 to_bf8x16(u32x4 a, u32x4 b, float scale) {
   }
   return r;
 }
+// 4 packed f16 pairs (8 values) -> 8 bf8 bytes
+__device__ __forceinline__ u32x2 to_bf8x8(unsigned p0, unsigned p1, unsigned p2, unsigned p3) {
+  s16x2 lo = {0, 0}, hi = {0, 0};
+  lo = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(lo, __builtin_bit_cast(f16x2_t, p0), 1.0f, false);
+  lo = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(lo, __builtin_bit_cast(f16x2_t, p1), 1.0f, true);
+  hi = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(hi, __builtin_bit_cast(f16x2_t, p2), 1.0f, false);
+  hi = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(hi, __builtin_bit_cast(f16x2_t, p3), 1.0f, true);
+  return (u32x2){__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+}
 // one packed f16 pair -> two bf8 bytes in the low (HI = false) or high half of `acc` (the builtin wants HI as a constant)
 template <bool HI> __device__ __forceinline__ unsigned bf8_pair(unsigned acc, unsigned pair) {
   if (HI) asm("v_cvt_scalef32_pk_bf8_f16 %0, %1, 1.0 op_sel:[0,0,1]" : "+v"(acc) : "v"(pair));
@@ -202,7 +211,7 @@ template <int K> __device__ __forceinline__ void lds_wait_frag(u32x4& r) {
 template <int F, bool X3, bool ENC, bool BWD, int NW, bool SG = false, bool H16 = false, bool S8 = false>
 __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs a) {
   static_assert(!S8 || (SG && H16), "8-bit stash: f16 backward kernel with in-kernel small gradients");
-  static_assert(!SG || (BWD && !ENC && !X3), "in-kernel small gradients: plain backward kernel without encoding");
+  static_assert(!SG || (BWD && !X3 && (!ENC || S8)), "in-kernel small gradients: plain backward kernel; with an encoding only the 8-bit-stash kernel");
   static_assert(!(H16 && (X3 || NW != 8)), "f16 hidden layers: 8-wave kernels only");
   static_assert(!(X3 && BWD), "the backward chain runs in plain bf16");
   static_assert(!(X3 && NW != 4), "the split mode needs 512 registers per wave");
@@ -367,6 +376,20 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
           else e[j] = (hh == 0 && j < 3) ? (j == 0 ? sp[cg].px : (j == 1 ? sp[cg].py : sp[cg].pz)) : 0.f;
         }
         split_frag(e, ehi[cg][q], elo[cg][q]);
+        if constexpr (BWD && ENC && S8) {
+          // 8-bit stash of the encoded inputs, layout of the activation stash ([row>>5][4 chunks of 16 columns][row&31][16 B], natural
+          // column order): this lane's 8 values are columns 16q + 8hh .. +7 = bytes 8hh.. of chunk q.  B operand of the first layer's
+          // weight gradient in k_wgrad_s8 (inputs rounded to bf8 like the hidden activations; averaged over all samples like them)
+          char* ep = (char*)a.stash_e + ((((size_t)(m[cg] >> 5) * 4 + q) << 5) + (m[cg] & 31)) * 16 + 8 * hh;
+          __builtin_nontemporal_store(to_bf8x8(pack2h(e[0], e[1]), pack2h(e[2], e[3]), pack2h(e[4], e[5]), pack2h(e[6], e[7])), (u32x2*)ep);
+          if (a.coef_cols > 0) {
+            float de[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) de[j] = enc_dcoef(16 * q + 8 * hh + j, sp[cg].px, sp[cg].py, sp[cg].pz, aux, a.n_freq);
+            __builtin_nontemporal_store(to_bf8x8(pack2h(de[0], de[1]), pack2h(de[2], de[3]), pack2h(de[4], de[5]), pack2h(de[6], de[7])),
+                                        (u32x2*)(ep + (size_t)a.stash_rows * 64));
+          }
+        }
         if (BWD && !SG) {
           if constexpr (ENC) {
             // 16-bit chunk-major stash of the encoded inputs (the B operand of the first layer's weight gradient in k_wgrad_bf16):
@@ -890,7 +913,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
 #pragma unroll
           for (int t = 0; t < NT; ++t) { dz[cg][t][0] = dn[cg][t][0]; dz[cg][t][1] = dn[cg][t][1]; }
       }
-      if constexpr (SG) {
+      if constexpr (SG && !ENC) {
 #pragma unroll
         for (int cg = 0; cg < NCG; ++cg) {
           float* rec = a.small_part + (size_t)(m[cg] >> 5) * (3 * F + 8);
@@ -917,7 +940,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
             *(f32x2*)(rec + 3 * F + 4) = (f32x2){dy, dzz};
           }
         }
-      } else {
+      } else {      // encoded inputs are not affine in the ray parameter: dZ_0 is stashed and contracted with the input stash (k_wgrad_*)
 #pragma unroll
         for (int t = 0; t < NT; ++t) stash_dz_tile(0, t);
       }
@@ -1147,10 +1170,16 @@ __global__ void __launch_bounds__(512) k_wgrad_s8(const WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, col = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int layer = blockIdx.y + 1, split = blockIdx.x;
+  // blockIdx.y < N: hidden layer blockIdx.y + 1.  enc16 (encoded inputs): blockIdx.y = N is the FIRST layer - A = dZ'_0, B = the 8-bit stash
+  // of the 64 input columns (4 chunk columns, natural column order) - and blockIdx.y = N + 1 the fourier-coefficient contraction
+  // (B = d(enc)/d(coef)/(2 pi)); both produce the two left-most column tiles only.
+  const int first = (int)blockIdx.y - a.n_hidden;           // < 0: hidden layer
+  const int layer = first < 0 ? (int)blockIdx.y + 1 : 0, split = blockIdx.x;
+  const int slot = first <= 0 ? layer : a.n_hidden + 1;     // partial slot
   const int E = wgrad_scale_exp(a.gmax);
   const char* A = (const char*)a.stash_dz + (size_t)layer * a.stride_rows * F;
-  const char* B = (const char*)a.stash_h + (size_t)(layer - 1) * a.stride_rows * F;
+  const char* B = first < 0 ? (const char*)a.stash_h + (size_t)(layer - 1) * a.stride_rows * F
+                            : (const char*)a.stash_e + (size_t)first * a.stride_rows * 64;
   int64_t r0 = (int64_t)split * a.rows_per_split;
   int64_t r1 = r0 + a.rows_per_split;
   if (r1 > a.rows) r1 = a.rows;
@@ -1174,7 +1203,12 @@ __global__ void __launch_bounds__(512) k_wgrad_s8(const WgradArgs a) {
     for (int c = wave; c < NCH; c += 8) {
       const size_t src = ((((size_t)(g0 + hh) * NCH + c) << 5) + col) << 4;
       __builtin_amdgcn_global_load_lds(GPTR(A + src), LPTR(dA + c * CS), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(GPTR(B + src), LPTR(dB + c * CS), 16, 0, 0);
+      if (first < 0) __builtin_amdgcn_global_load_lds(GPTR(B + src), LPTR(dB + c * CS), 16, 0, 0);
+      else {      // input stash: 4 chunk columns; every wave still issues one B piece per A piece (column c mod 4, identical data where
+                  // two waves meet), so that the counted vmcnt below holds for every grid row
+        const size_t srcb = ((((size_t)(g0 + hh) * 4 + (c & 3)) << 5) + col) << 4;
+        __builtin_amdgcn_global_load_lds(GPTR(B + srcb), LPTR(dB + (c & 3) * CS), 16, 0, 0);
+      }
     }
     if (wave == 0) __builtin_amdgcn_global_load_lds(GPTR(a.gexp + g0 + hh), LPTR(lds + GOFF + buf * (KB * 4)), 4, 0, 0);
   };
@@ -1232,8 +1266,8 @@ __global__ void __launch_bounds__(512) k_wgrad_s8(const WgradArgs a) {
       }
     }
   }
-  float* P = a.partial + ((size_t)layer * a.n_splits + split) * F * F;
-  if (active) {
+  float* P = a.partial + ((size_t)slot * a.n_splits + split) * F * F;
+  if (active && first < 0) {
 #pragma unroll
     for (int i = 0; i < TR; ++i)
 #pragma unroll
@@ -1241,8 +1275,18 @@ __global__ void __launch_bounds__(512) k_wgrad_s8(const WgradArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           P[(size_t)fperm8(32 * (wr * TR + i) + rowperm(r) + 4 * hh) * F + fperm8(32 * (wc * TC + j) + col)] = acc[i][j][r];
+  } else if (active) {      // first layer: rows [F] x k0pad = 64 input columns in natural order (the layout k_reduce_w expects)
+#pragma unroll
+    for (int i = 0; i < TR; ++i)
+#pragma unroll
+      for (int j = 0; j < TC; ++j)
+        if (wc * TC + j < 2) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            P[(size_t)fperm8(32 * (wr * TR + i) + rowperm(r) + 4 * hh) * a.k0pad + 32 * (wc * TC + j) + col] = acc[i][j][r];
+        }
   }
-  if (has_bias && col == 0) {        // every column of accb holds the row sums
+  if (has_bias && col == 0 && first <= 0) {        // every column of accb holds the row sums
 #pragma unroll
     for (int r = 0; r < 16; ++r)
       a.partial2[((size_t)layer * a.n_splits + split) * (F + 4) + fperm8(32 * (wr * TR + wc) + rowperm(r) + 4 * hh)] = accb[r];
@@ -1340,7 +1384,13 @@ __global__ void __launch_bounds__(F) k_small_from_groups(const WgradArgs a) {
 #pragma unroll 4
   for (int64_t g = g0; g < g1; ++g) {
     const float* rec = base + g * RS;
-    const float sw = rec[p], s0 = rec[F + p], s1 = rec[2 * F + p];
+    const float sw = rec[p];
+    if (a.enc16) {          // encoded inputs: only the output layer's sums are in the records (first layer: k_wgrad_s8)
+      aw += sw;
+      sg += rec[3 * F + 6];
+      continue;
+    }
+    const float s0 = rec[F + p], s1 = rec[2 * F + p];
     const f32x4 c4 = *(const f32x4*)(rec + 3 * F);
     const f32x4 d4 = *(const f32x4*)(rec + 3 * F + 4);      // dy, dz, sum g, -
     aw += sw;

@@ -467,9 +467,10 @@ def test_argument_validation():
 # ------------------------------------------------------------------------------------------------
 # Encoded inputs (BARF) through forward AND backward; hierarchical pipeline; full-size properties; graphs
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("prec", ["f32", "bf16x3", "f16", "bf16"])
+@pytest.mark.parametrize("prec", ["f32", "bf16x3", "f16", "f16s8", "bf16"])
 def test_barf_backward_vs_oracle(prec):
-    """K0 = 33 encoded inputs: first-layer MFMA k-steps, encoded-input stash and first-layer weight gradient."""
+    """K0 = 33 encoded inputs: first-layer MFMA k-steps, encoded-input stash (fp32 / 16-bit / bf8) and the first-layer weight
+    gradient as an extra grid row of the weight-gradient kernels (k_wgrad_f32 / k_wgrad_bf16 / k_wgrad_s8)."""
     from oracle import angio_oracle as orc
     from nerf_for_angiography_amd.render import render_rays
     torch.manual_seed(11)
@@ -852,7 +853,7 @@ def test_training_precision_tracks_fp32_convergence():
             else:
                 loss, _ = train_step_mse(m, projection_spec(poses[i], W, W, 13.0 * W, S, near, far), targets[i])
             opt.step()
-            losses.append(float(loss))
+            losses.append(float(loss.detach()))
         curves[prec] = np.array(losses)
     assert curves["f32"][-8:].mean() < 0.5 * curves["f32"][:8].mean()            # it does train
     for prec in ("f16", "f16s8"):
