@@ -44,6 +44,25 @@ __device__ __forceinline__ int wgrad_scale_exp(const uint32_t* gmax_bits) {
 
 // One element of CPPN.pos_enc's output (model/CPPN.py:207-234) for input point (px,py,pz).
 // aux (LDS): BARF [freq(3L) | weight(3L)], FOURIER [coef(3L)].
+// sin(v) (want_cos = false) or cos(v) for the encodings: three-constant Cody-Waite reduction by pi/2 with FMAs and the degree-7 /
+// degree-8 minimax polynomials on [-pi/4, pi/4] (cephes sinf/cosf) - a dozen instructions, no branches.  libm's sinf/cosf, inlined
+// 32 times per lane (each with its large-argument path and scratch array) or called out of line (registers spilled around every
+// call), made the encoding the dominant cost of a tile's prologue.  Accuracy: <= 1e-7 absolute up to |v| = 1e5 (measured against
+// float64), degrading gracefully beyond as k = rint(v 2/pi) loses its last bits; fp32 arguments above 2^23 carry less than one
+// radian of information in any implementation.  Arguments here: 2^k pi x (BARF) and 2 pi x coef (fourier), |x| of a few hundred.
+__device__ __forceinline__ float enc_sincos(float v, bool want_cos) {
+  const float kf = rintf(v * 0.636619772367581343f);          // 2 / pi
+  float r = fmaf(kf, -1.57079637050628662109375f, v);         // pi/2 = C1 + C2 + C3
+  r = fmaf(kf, 4.37113900018624283e-8f, r);
+  r = fmaf(kf, 1.71512449441083685e-15f, r);
+  const int q = ((int)kf + (want_cos ? 1 : 0)) & 3;
+  const float z = r * r;
+  const float sp = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+  const float cp = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f) * z, z, fmaf(-0.5f, z, 1.f));
+  const float res = (q & 1) ? cp : sp;
+  return (q & 2) ? -res : res;
+}
+
 __device__ __forceinline__ float enc_value(int k, float px, float py, float pz, const float* aux,
                                            int enc, int n_freq, int k0) {
   if (k < 3) return k == 0 ? px : (k == 1 ? py : pz);
@@ -56,12 +75,12 @@ __device__ __forceinline__ float enc_value(int k, float px, float py, float pz, 
   const float x = c == 0 ? px : (c == 1 ? py : pz);
   if (enc == 1) {  // barf: w * sin|cos(freq * x)
     const float v = __fmul_rn(aux[m], x);
-    const float s = is_cos ? cosf(v) : sinf(v);
+    const float s = enc_sincos(v, is_cos);
     return __fmul_rn(aux[nb + m], s);
   }
   // fourier: sin|cos(((2*pi) * x) * coef)
   const float v = __fmul_rn(__fmul_rn(6.283185307179586f, x), aux[m]);
-  return is_cos ? cosf(v) : sinf(v);
+  return enc_sincos(v, is_cos);
 }
 
 // d(enc)/d(coef) / (2 pi) of the fourier encoding (fourier_pos_enc, model/CPPN.py:320-327), as 2*nb extra "input columns":
@@ -75,7 +94,7 @@ __device__ __forceinline__ float enc_dcoef(int k, float px, float py, float pz, 
   const int c = m % 3;
   const float x = c == 0 ? px : (c == 1 ? py : pz);
   const float v = __fmul_rn(__fmul_rn(6.283185307179586f, x), aux[m]);
-  return second ? -x * sinf(v) : x * cosf(v);
+  return second ? -x * enc_sincos(v, false) : x * enc_sincos(v, true);
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }

@@ -21,6 +21,9 @@ md = dict(num_early_layers=layers, num_late_layers=0, num_filters=width, num_inp
           num_input_channels_views=0, use_bias=True, pos_enc=os.environ.get("ENC", "none"), pos_enc_basis=5, act_func="relu", fourier_sigma=5,
           num_img=1, device=dev, precision=os.environ.get("PREC", "f16s8"))
 m = CPPN(md).to(dev)
+if os.environ.get("AFX_VARIANT"):
+    from nerf_for_angiography_amd.engine import Engine
+    m._engine = Engine(width, layers, md["pos_enc"], 5 if md["pos_enc"] != "none" else 0, variant=os.environ["AFX_VARIANT"])
 if md["pos_enc"] == "barf":
     m.update_barf_alpha(2.5, "pts")
 opt = torch.optim.Adam(m.parameters(), lr=1e-4)
