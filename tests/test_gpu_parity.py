@@ -75,6 +75,28 @@ def test_mlp_forward_fourier_golden(golden):
     assert rel_l2(y.cpu().numpy(), g["y"]) < 5e-5
 
 
+@pytest.mark.parametrize("enc", ["barf", "fourier"])
+def test_encoding_large_coordinates(enc):
+    """The kernels' own sin/cos (Cody-Waite reduction + minimax polynomials, csrc enc_sincos) at world-scale coordinates:
+    |x| up to 2 000 puts the BARF arguments 2^k pi x at 1e5 rad.  Encoded first-layer inputs are compared through a linear probe:
+    a 0-hidden-layer-equivalent check is not available, so the comparison is on the MLP output against the CPU oracle."""
+    from oracle import angio_oracle as orc
+    torch.manual_seed(21)
+    m = make_model(2, 64, enc, precision="f32")
+    if enc == "barf":
+        m.update_barf_alpha(5.0, "pts")
+    else:
+        with torch.no_grad():
+            m.fourier_coefficients.mul_(0.02)          # arguments 2 pi x coef ~ 1e3 rad
+    pts = (torch.rand(8192, 3) * 2 - 1) * 2000.0
+    cfg = dict(num_early_layers=2, num_filters=64, pos_enc=enc, pos_enc_basis=5)
+    params = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    want = orc.cppn_forward(pts, cfg, params).reshape(-1).numpy()
+    with torch.no_grad():
+        got = m(pts.to(DEV)).reshape(-1).cpu().numpy()
+    assert rel_l2(got, want) < 5e-5
+
+
 # Tolerances (relative L2) per arithmetic mode.  "f32": exact-fp32 MFMA.  "bf16x3": split-bf16 forward
 # (fp32-grade, meets the 1e-4 north-star bar on projections / density grids) with bf16 gradients.
 # "f16": THE TRAINING / BENCHMARK PRECISION - f16 operands in the hidden layers (first layer split bf16), fp32
