@@ -11,12 +11,14 @@ from nerf_for_angiography_amd.nerf.nerf_helpers import fine_sampling
 from nerf_for_angiography_amd.phantomdata.helpers import get_ray_values
 
 dev = torch.device("cuda:0")
-def model(prec="f16s8"):
+def model(prec="f16s8", enc="none"):
     torch.manual_seed(0)
     md = dict(num_early_layers=8, num_late_layers=0, num_filters=256, num_input_channels=3, num_output_channels=1,
-              num_input_channels_views=0, use_bias=True, pos_enc="none", pos_enc_basis=5, act_func="relu", fourier_sigma=5,
+              num_input_channels_views=0, use_bias=True, pos_enc=enc, pos_enc_basis=5, act_func="relu", fourier_sigma=5,
               num_img=1, device=dev, precision=prec)
     m = CPPN(md).to(dev)
+    if enc == "barf":
+        m.update_barf_alpha(2.5, "pts")
     with torch.no_grad():
         m.output_linear[0].weight.mul_(4.0); m.output_linear[0].bias.fill_(-5.0)
     m.engine.max_workspace_bytes = 128 << 30      # as bench.py: 288 GB of HBM per GPU, few large ray chunks
@@ -39,8 +41,22 @@ for name, (W, S) in {"C2 256^2x64": (256, 64), "C4 512^2x128 (1 GPU)": (512, 128
     t = timeit(step)
     out[name] = dict(ms_per_step=round(t * 1e3, 2), ray_samples_per_s=round(W * W * S / t / 1e6, 1))
     print(name, out[name], flush=True)
+# C4 with positional encodings (33 encoded inputs, L = 5): BARF (fixed weights) and fourier with TRAINABLE coefficients
+for enc in ("barf", "fourier"):
+    W, S = 512, 128
+    m = opt = None; import gc; gc.collect(); torch.cuda.empty_cache()       # the previous model's 128 GiB workspace
+    m = model(enc=enc); opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    o, d, m44, _, _ = get_ray_values(20.0, 0.0, 0.0, np.array([0, 0, 1500.0]), W, W, 13.0 * W, dev)
+    pose = torch.from_numpy(m44[None]).to(dev); tgt = torch.rand(W * W, device=dev)
+    spec = projection_spec(pose, W, W, 13.0 * W, S, 1400.0, 1600.0)
+    def step_e():
+        opt.zero_grad(set_to_none=True); train_step_mse(m, spec, tgt); opt.step()
+    t = timeit(step_e)
+    out[f"C4 512^2x128 {enc} L=5"] = dict(ms_per_step=round(t * 1e3, 2), ray_samples_per_s=round(W * W * S / t / 1e6, 1))
+    print(enc, out[f"C4 512^2x128 {enc} L=5"], flush=True)
 # C3: hierarchical coarse (128) + fine (128 + 64), dense convention with per-ray depths, autograd backward
 W, SC, NF = 512, 128, 64
+m = opt = None; gc.collect(); torch.cuda.empty_cache()
 m = model(); opt = torch.optim.Adam(m.parameters(), lr=1e-4)
 o, d, m44, _, _ = get_ray_values(20.0, 0.0, 0.0, np.array([0, 0, 1500.0]), W, W, 13.0 * W, dev)
 o, d = o.reshape(-1, 3).float().contiguous(), d.reshape(-1, 3).float().contiguous()
