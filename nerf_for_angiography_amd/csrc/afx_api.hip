@@ -555,6 +555,17 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
   const int64_t tiles = (a.n_total + TILE - 1) / TILE;
   int64_t chunk = (int64_t)((ws_bytes - fixed - 1024) / B.per_tile_bytes);      // 1 KiB slack for buffer alignment
   if (chunk > tiles) chunk = tiles;
+  if (b16) {
+    // The 16-/8-bit chain kernels address a layer's stash with 32-bit byte offsets (one VGPR per lane instead of two): a chunk's
+    // layer plane must stay below 4 GiB.  (Until round 2 nothing enforced this: with a 128 GiB workspace the 512^2 x 128 projection
+    // ran as 2 chunks of 8.3 GB planes and the rows beyond 4 GiB wrapped onto the first ones - wrong weight gradients, same timing.)
+    const int64_t max_tiles = (int64_t)((((uint64_t)1 << 32) - 65536) / ((uint64_t)TILE * F * esz));
+    if (chunk > max_tiles) chunk = max_tiles;
+  }
+  if (chunk < tiles) {      // equal chunks instead of full ones and a remainder
+    const int64_t n_chunks = (tiles + chunk - 1) / chunk;
+    chunk = (tiles + n_chunks - 1) / n_chunks;
+  }
   // Overlap mode: two half-size stash buffers; the weight-gradient kernels of chunk i run on a side stream while
   // the chain kernel of chunk i+1 runs on the caller's stream (one is MFMA/HBM-write heavy, the other HBM-read
   // bound).  Fork/join with events only; the side stream always rejoins the caller's stream before returning.

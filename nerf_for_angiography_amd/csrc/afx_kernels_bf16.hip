@@ -72,7 +72,7 @@ __device__ __forceinline__ void split_frag(const float* v, u32x4& hi, u32x4& lo)
 // epilogue VALU work, barrier and LDS latencies.
 // byte offset of the 16-byte chunk `ch` (8 stash positions) of stash row `r` inside one layer's stash
 template <int F> __device__ __forceinline__ uint32_t stash_off(uint32_t r, int ch) {
-  return ((((r >> 5) * (F / 8) + ch) << 5) + (r & 31)) << 4;      // < 2^32: the host bounds a layer's stash
+  return ((((r >> 5) * (F / 8) + ch) << 5) + (r & 31)) << 4;      // < 2^32: run_backward bounds a chunk's layer plane to 4 GiB
 }
 
 // S8 (8-bit stash, f16 mode): H_l and dZ'_l = g_hat J_l are stashed as bf8 (e5m2: the top byte of the f16 pattern, same

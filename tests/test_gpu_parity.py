@@ -707,6 +707,35 @@ def test_production_build_is_bit_identical_to_the_safe_waits_build(prec):
         assert torch.equal(g, res[1][2][k]), k
 
 
+@pytest.mark.parametrize("prec", ["f16s8", "f16"])
+def test_large_chunks_keep_32bit_stash_offsets_in_range(prec):
+    """Regression: the 16-/8-bit chain kernels address a layer's stash with 32-bit offsets; a shallow model with a large
+    workspace used to get chunks whose layer plane exceeded 4 GiB (rows beyond it wrapped around: wrong weight gradients,
+    nothing else).  33.5 M samples, 1x256 MLP: with the default 24 GiB workspace the 4 stash planes of a chunk were 6 GiB (f16s8: one
+    chunk; f16: two) before the fix; compared with 3 GiB of workspace (small chunks)."""
+    from nerf_for_angiography_amd.render import train_step_mse, projection_spec
+    from nerf_for_angiography_amd.phantomdata.helpers import get_ray_values
+    W, S = 512, 128
+    _, _, m44, _, _ = get_ray_values(20.0, 0.0, 0.0, np.array([0, 0, 1500.0]), W, W, 13.0 * W, "cpu")
+    spec = projection_spec(torch.from_numpy(m44[None]).to(DEV), W, W, 13.0 * W, S, 1400.0, 1600.0)
+    tgt = torch.rand(W * W, generator=torch.Generator().manual_seed(3)).to(DEV)
+    grads = {}
+    for ws_gib in (24, 3):
+        torch.manual_seed(5)
+        m = make_model(1, 256, precision=prec)
+        with torch.no_grad():
+            m.output_linear[0].weight.mul_(4.0)
+            m.output_linear[0].bias.fill_(-5.0)
+        m.engine.max_workspace_bytes = ws_gib << 30
+        m.engine._workspace(ws_gib << 30, torch.device(DEV)).fill_(255)      # stale contents must not matter either
+        train_step_mse(m, spec, tgt)
+        grads[ws_gib] = torch.cat([p.grad.reshape(-1) for p in m.parameters() if p.grad is not None]).cpu().numpy()
+        assert np.isfinite(grads[ws_gib]).all()
+        del m
+        torch.cuda.empty_cache()
+    assert rel_l2(grads[24], grads[3]) < 1e-5          # chunking only changes the order of fp32 partial sums
+
+
 def test_c3_full_size_hierarchical():
     """BASELINE config C3: 512x512 rays, 128 coarse + 64 fine samples, 8x256.  The dense convention's 1e10 tail makes
     rgb_map == 0 at ordinary weights, so the output bias is -26 as in the reference-captured dense26 fixture.

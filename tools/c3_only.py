@@ -24,7 +24,14 @@ with torch.no_grad():
 m.engine.max_workspace_bytes = 128 << 30
 opt = torch.optim.Adam(m.parameters(), lr=1e-4)
 if os.environ.get("WS_FIRST"):
-    m.engine._workspace(128 << 30, dev)      # allocate the backward workspace before anything else of size
+    ws = m.engine._workspace(128 << 30, dev)      # allocate the backward workspace before anything else of size
+    fill = os.environ.get("WS_FILL")
+    if fill == "zero":
+        ws.zero_()
+    elif fill == "rand":      # random bytes, 8 GiB at a time
+        for i in range(0, ws.numel(), 8 << 30):
+            ws[i:i + (8 << 30)].random_(0, 256)
+    del ws
 W, SC, NF = 512, 128, 64
 o, d, m44, _, _ = get_ray_values(20.0, 0.0, 0.0, np.array([0, 0, 1500.0]), W, W, 13.0 * W, dev)
 o, d = o.reshape(-1, 3).float().contiguous(), d.reshape(-1, 3).float().contiguous()
@@ -37,7 +44,10 @@ def step3():
         coarse = render_rays(m, o, d, mode="dense", z=z, want_aux=True)
     rgb, dep, ent = fine_sampling(z, coarse.weights, o, d, m, None, NF, 131072)
     torch.nn.functional.mse_loss(rgb, tgt).backward(); opt.step()
-for rep in range(3):
+step3(); torch.cuda.synchronize()
+gr = torch.cat([p.grad.reshape(-1) for p in m.parameters() if p.grad is not None])
+print("after one step: grad |max|", float(gr.abs().max()), "NaNs", int(torch.isnan(gr).sum()), "weights |sum|", float(sum(p.double().abs().sum() for p in m.parameters())), flush=True)
+for rep in range(int(os.environ.get("REPS", "3"))):
     step3(); torch.cuda.synchronize()
     if PROF:
         for k in ("chain_fwd", "chain_bwd", "wgrad"): m.engine.profile_read(k)
