@@ -243,7 +243,7 @@ struct BwdLayout {
   size_t fixed_bytes, per_tile_bytes;
 };
 static const int kSplits = 64;
-static const int kSmallBlocks = 256;   // blocks (and partial records) of k_small_grads_bf16
+static const int kSmallBlocks = 1024;  // blocks (and partial records) of k_small_grads_bf16 / k_small_from_groups: 4 per CU, their record loop is latency-bound
 static BwdLayout bwd_layout(const afx_ctx* c, int prec, int64_t n_rays) {
   const size_t F = c->d.width, N = c->d.n_hidden;
   BwdLayout B;
