@@ -52,9 +52,9 @@ enum { AFX_ENC_NONE = 0, AFX_ENC_BARF = 1, AFX_ENC_FOURIER = 2 };
  *            (H_l, and the normalised chain J_l) as bf8 (e5m2) instead of f16:
  *            half the HBM round trip that bounds a training step.  Forward
  *            results are identical to F16; weight gradients carry the extra
- *            bf8 rounding of the two contraction operands: zero-mean, averaged
- *            over the samples - 6e-3 relative L2 of the whole gradient on random
- *            targets, 2.8e-2 on the benchmark's phantom targets (F16: 5e-4).  Rays mode (with an input encoding
+ *            bf8 rounding of the two contraction operands (H to nearest, dZ'
+ *            stochastically: its errors are systematic otherwise), averaged over
+ *            the samples: 2e-3 relative L2 of the whole gradient (F16: 5e-4).  Rays mode (with an input encoding
  *            the encoded inputs are stashed as bf8 as well); points mode
  *            (afx_mlp_backward) runs exactly as F16.                           */
 enum { AFX_PREC_F32 = 0, AFX_PREC_BF16X3 = 1, AFX_PREC_BF16 = 2, AFX_PREC_F16 = 3, AFX_PREC_F16S8 = 4 };
