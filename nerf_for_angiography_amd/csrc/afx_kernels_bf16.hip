@@ -841,8 +841,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
             // layer's dZ'_N = g_hat w_out (masked) has the SAME mantissa for every sample whose g_hat is the same, and on real targets
             // (uniform background, near-constant density along a ray) that is most samples - the same relative error everywhere,
             // nothing averages out: that one layer carried 3.7e-2 of gradient error on bench.py's phantom targets (6e-3 on random
-            // targets, like the other layers).  Random bits: a Weyl sequence per lane and tile seeded by a hash of the sample
-            // index - deterministic, so the step stays bit-reproducible.
+            // targets, like the other layers).  Random bits: one hashed word per lane and tile (sample index, layer, tile) - deterministic,
+            // so the step stays bit-reproducible.
             const unsigned src[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
             unsigned h = ((unsigned)n[cg] * 0x9E3779B1u) ^ ((unsigned)(l * NT + t) * 0x85EBCA77u + (unsigned)hh * 0xC2B2AE3Du);
             h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 13;
@@ -850,9 +850,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
               const f16x2_t pr = __builtin_bit_cast(f16x2_t, src[j >> 1]);
-              r[j >> 2] = sr_bf8(r[j >> 2], pr[j & 1], h, j & 3);
-              h += 0x9E3779B9u;
-            }
+              r[j >> 2] = sr_bf8(r[j >> 2], pr[j & 1], h, j & 3);      // one random word per lane and tile: the 16 features of a sample share
+            }                                                         // the rounding threshold, which biases no sum over samples
             const u32x4 r8 = {r[0], r[1], r[2], r[3]};
             stash_store((char*)a.stash_dz + (size_t)l * a.stash_rows * F + (so[cg] + (uint32_t)(2 * t) * 512u), r8);
           } else {
