@@ -736,6 +736,54 @@ def test_large_chunks_keep_32bit_stash_offsets_in_range(prec):
     assert rel_l2(grads[24], grads[3]) < 1e-5          # chunking only changes the order of fp32 partial sums
 
 
+@pytest.mark.parametrize("prec", ["f16s8", "f16", "bf16", "f32"])
+def test_results_do_not_depend_on_stale_workspace(prec):
+    """Every byte a backward kernel reads must have been written by the same call: the same step with the workspace pre-filled
+    with zeros, with 0xFF bytes (NaN patterns in every format) and with random bytes gives bit-identical pixels and gradients -
+    several ray chunks, rays mode with and without the fused step, with and without an input encoding."""
+    from nerf_for_angiography_amd.render import render_rays, train_step_mse
+    from nerf_for_angiography_amd.engine import RenderSpec
+    dev = torch.device(DEV)
+    ws_bytes = 48 << 20
+
+    def run(fill, mode, enc, n_samples):
+        torch.manual_seed(0)
+        m = make_model(3, 64, enc, precision=prec)
+        with torch.no_grad():
+            m.output_linear[0].weight.mul_(4.0)
+            m.output_linear[0].bias.fill_(-4.0)
+        m.engine.max_workspace_bytes = ws_bytes
+        ws = m.engine._workspace(ws_bytes, dev)
+        if fill == "zero":
+            ws.zero_()
+        elif fill == "ff":
+            ws.fill_(255)
+        else:
+            ws.random_(0, 256)
+        g = torch.Generator().manual_seed(1)
+        r = 1500
+        o = (torch.tensor([[0.0, 0.0, 1.5]]).repeat(r, 1) + torch.randn(r, 3, generator=g) * 0.01).to(dev)
+        d = torch.nn.functional.normalize(torch.randn(r, 3, generator=g) * 0.2 + torch.tensor([0, 0, -1.0]), dim=-1).to(dev)
+        tgt = torch.rand(r, generator=g).to(dev)
+        if mode == "fused":
+            _, pix = train_step_mse(m, RenderSpec(n_rays=r, n_samples=n_samples, origins=o, dirs=d, mode="acc", t_near=0.5, t_far=2.5), tgt)
+        else:
+            out = render_rays(m, o, d, n_samples, 0.5, 2.5, mode="acc")
+            torch.nn.functional.mse_loss(out.rgb_map, tgt).backward()
+            pix = out.rgb_map.detach()
+        return pix.cpu(), torch.cat([p.grad.reshape(-1) for p in m.parameters() if p.grad is not None]).cpu()
+
+    for mode, n_samples in (("autograd", 96), ("fused", 64)):
+        if mode == "fused" and prec == "f32":
+            continue
+        for enc in ("none", "barf"):
+            ref = run("zero", mode, enc, n_samples)
+            assert float(ref[1].abs().max()) > 0
+            for fill in ("ff", "rand"):
+                got = run(fill, mode, enc, n_samples)
+                assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), (mode, enc, fill)
+
+
 def test_c3_full_size_hierarchical():
     """BASELINE config C3: 512x512 rays, 128 coarse + 64 fine samples, 8x256.  The dense convention's 1e10 tail makes
     rgb_map == 0 at ordinary weights, so the output bias is -26 as in the reference-captured dense26 fixture.
