@@ -765,7 +765,12 @@ def test_results_do_not_depend_on_stale_workspace(prec):
         o = (torch.tensor([[0.0, 0.0, 1.5]]).repeat(r, 1) + torch.randn(r, 3, generator=g) * 0.01).to(dev)
         d = torch.nn.functional.normalize(torch.randn(r, 3, generator=g) * 0.2 + torch.tensor([0, 0, -1.0]), dim=-1).to(dev)
         tgt = torch.rand(r, generator=g).to(dev)
-        if mode == "fused":
+        if mode == "points":
+            pts = (torch.rand(40000, 3, generator=g) * 2 - 1).to(dev)
+            pix = m(pts)
+            (pix * torch.randn(40000, 1, generator=g).to(dev)).sum().backward()
+            pix = pix.detach()
+        elif mode == "fused":
             _, pix = train_step_mse(m, RenderSpec(n_rays=r, n_samples=n_samples, origins=o, dirs=d, mode="acc", t_near=0.5, t_far=2.5), tgt)
         else:
             out = render_rays(m, o, d, n_samples, 0.5, 2.5, mode="acc")
@@ -773,7 +778,7 @@ def test_results_do_not_depend_on_stale_workspace(prec):
             pix = out.rgb_map.detach()
         return pix.cpu(), torch.cat([p.grad.reshape(-1) for p in m.parameters() if p.grad is not None]).cpu()
 
-    for mode, n_samples in (("autograd", 96), ("fused", 64)):
+    for mode, n_samples in (("autograd", 96), ("fused", 64), ("points", 0)):
         if mode == "fused" and prec == "f32":
             continue
         for enc in ("none", "barf"):
