@@ -146,7 +146,7 @@ def main():
     ap.add_argument("--cpu-rays", type=int, default=4096)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--workspace-gib", type=float, default=128.0,
-                    help="backward stash workspace per GPU (288 GB HBM: 128 GiB holds the 512^2x128 projection in 3 ray chunks)")
+                    help="backward stash workspace per GPU (an upper limit: the engine takes what two 4 GiB-per-layer-plane chunks need, 79 GB for the 512^2x128 projection)")
     ap.add_argument("--unfused", action="store_true",
                     help="render -> mse_loss -> autograd backward (forward rendered separately) instead of the fused train step")
     ap.add_argument("--no-grad-check", action="store_true", help="skip the full-size gradient check against the fp32 kernels (about 2 s)")

@@ -4,6 +4,7 @@
 #include <stdarg.h>
 #include <stdlib.h>
 #include <stdio.h>
+#include <algorithm>
 #include <string>
 #include <vector>
 #include "../../include/afx.h"
@@ -12,6 +13,7 @@
 #include "afx_kernels_bf16.hip"
 #include "afx_kernels_grid.hip"
 #include "afx_inst.h"
+#include <algorithm>
 #include <set>
 
 // The 16-bit chain kernels are compiled in their own translation units (afx_inst_chain16.hip); -DAFX_SINGLE_TU
@@ -274,7 +276,16 @@ extern "C" int64_t afx_query(const afx_ctx* c, int what, int64_t a0, int64_t a1,
     case AFX_Q_BWD_WORKSPACE_FULL: {
       BwdLayout B = bwd_layout(c, (int)a2, a0);
       const int64_t samples = a0 > 0 ? a0 * s_pad_of((int)a1) : a1;
-      const int64_t tiles = (samples + bwd_tile((int)a2) - 1) / bwd_tile((int)a2);
+      int64_t tiles = (samples + bwd_tile((int)a2) - 1) / bwd_tile((int)a2);
+      if (is_bf16((int)a2)) {      // a chunk never exceeds the 4 GiB layer plane the 32-bit stash offsets reach (run_backward): more is never used
+        const uint64_t plane_rows = ((uint64_t)1 << 32) / ((uint64_t)c->d.width * 2);
+        size_t need = (size_t)std::min<int64_t>(tiles, (int64_t)(plane_rows / bwd_tile((int)a2))) * B.per_tile_bytes;
+        if ((int)a2 == AFX_PREC_F16S8 && c->small_in_kernel) {      // rays mode stashes 1-byte elements: twice the rows per plane, ~half the bytes per row
+          const size_t per8 = (size_t)256 * (2 * ((size_t)c->d.n_hidden + 1) * c->d.width + 4 * 16 * nk0_of(c) + 4);
+          need = std::max(need, (size_t)std::min<int64_t>(tiles, (int64_t)(2 * plane_rows / 256)) * per8);
+        }
+        return (int64_t)(B.fixed_bytes + need + 1024);
+      }
       return (int64_t)(B.fixed_bytes + (size_t)tiles * B.per_tile_bytes + 1024);
     }
   }
@@ -559,7 +570,7 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
     // The 16-/8-bit chain kernels address a layer's stash with 32-bit byte offsets (one VGPR per lane instead of two): a chunk's
     // layer plane must stay below 4 GiB.  (Until round 2 nothing enforced this: with a 128 GiB workspace the 512^2 x 128 projection
     // ran as 2 chunks of 8.3 GB planes and the rows beyond 4 GiB wrapped onto the first ones - wrong weight gradients, same timing.)
-    const int64_t max_tiles = (int64_t)((((uint64_t)1 << 32) - 65536) / ((uint64_t)TILE * F * esz));
+    const int64_t max_tiles = (int64_t)(((uint64_t)1 << 32) / ((uint64_t)TILE * F * esz));      // the largest offset used is plane - 16
     if (chunk > max_tiles) chunk = max_tiles;
   }
   if (chunk < tiles) {      // equal chunks instead of full ones and a remainder
