@@ -14,11 +14,13 @@ focal, near, far = 13.0 * W, 1400.0, 1600.0
 def model(prec):
     torch.manual_seed(0)
     md = dict(num_early_layers=8, num_late_layers=0, num_filters=256, num_input_channels=3, num_output_channels=1,
-              num_input_channels_views=0, use_bias=True, pos_enc="none", pos_enc_basis=5, act_func="relu", fourier_sigma=5,
+              num_input_channels_views=0, use_bias=True, pos_enc=os.environ.get("ENC", "none"), pos_enc_basis=5, act_func="relu", fourier_sigma=5,
               num_img=1, device=dev, precision=prec)
     m = CPPN(md).to(dev)
     with torch.no_grad():
         m.output_linear[0].weight.mul_(4.0); m.output_linear[0].bias.fill_(-5.0)
+    if md["pos_enc"] == "barf":
+        m.update_barf_alpha(2.5, "pts")
     m.engine.max_workspace_bytes = 48 << 30
     return m
 _, _, m44, _, _ = get_ray_values(0.0, 0.0, 0.0, np.array([0, 0, 1500.0]), 2, 2, focal, "cpu")
