@@ -71,6 +71,13 @@ def test_context_queries_and_validation_without_gpu():
         assert lib.afx_query(h, _lib.Q_PREPARED_BYTES, prec, 0, 0) > 1 << 20
     full = lib.afx_query(h, _lib.Q_BWD_WORKSPACE_FULL, 4096, 128, 2)
     assert full > lib.afx_query(h, _lib.Q_BWD_WORKSPACE_MIN, 4096, 0, 2) > 0
+    # 16-/8-bit kernels: a chunk's per-layer stash plane stops at 4 GiB (32-bit stash offsets), so the FULL size saturates there:
+    # 8x256 -> 32 768 tiles of 256 samples at 2 bytes per element, 65 536 tiles at 1 byte (f16s8)
+    for prec, tiles in ((_lib.PREC["f16"], 32768), (_lib.PREC["bf16"], 32768), (_lib.PREC["f16s8"], 65536)):
+        at_cap = lib.afx_query(h, _lib.Q_BWD_WORKSPACE_FULL, 0, tiles * 256, prec)
+        assert lib.afx_query(h, _lib.Q_BWD_WORKSPACE_FULL, 0, 4 * tiles * 256, prec) == at_cap
+        assert lib.afx_query(h, _lib.Q_BWD_WORKSPACE_FULL, 0, tiles * 256 // 2, prec) < at_cap
+    assert lib.afx_query(h, _lib.Q_BWD_WORKSPACE_FULL, 0, 1 << 30, _lib.PREC["f32"]) > lib.afx_query(h, _lib.Q_BWD_WORKSPACE_FULL, 0, 1 << 29, _lib.PREC["f32"])
     lib.afx_destroy(h)
     # bad descriptors are refused with a message
     for bad in (_lib.ModelDesc(2, 0, 0, 256, 8), _lib.ModelDesc(3, 0, 0, 100, 8), _lib.ModelDesc(3, 1, 0, 64, 4),
