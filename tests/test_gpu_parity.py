@@ -620,6 +620,51 @@ def _bench_model(precision, seed=0):
     return m
 
 
+@pytest.mark.parametrize("enc", ["barf", "fourier"])
+def test_full_size_encoded_gradients(enc):
+    """BASELINE size C4 with a positional encoding (33 encoded inputs) at the default precision: the fused f16s8 step (bf8 input
+    stash, first layer and - fourier - the coefficient contraction as rows of k_wgrad_s8) against the fp32-mode backward over all
+    33.5 M samples; pixels against the fp32 forward."""
+    from nerf_for_angiography_amd.render import render_projection, train_step_mse, projection_spec
+    from nerf_for_angiography_amd.phantomdata.helpers import get_ray_values
+    W, S = 512, 128
+    _, _, m44, _, _ = get_ray_values(24.0, 8.0, 0.0, np.array([0, 0, 1500.0]), W, W, 13.0 * W, "cpu")
+    poses = torch.from_numpy(m44[None]).to(DEV)
+    tgt = torch.rand(W * W, generator=torch.Generator().manual_seed(9)).to(DEV)
+
+    def model(prec):
+        torch.manual_seed(0)
+        m = make_model(8, 256, enc, precision=prec)
+        if enc == "barf":
+            m.update_barf_alpha(2.5, "pts")
+        else:
+            with torch.no_grad():
+                m.fourier_coefficients.mul_(0.002)         # 2 pi x coef of a few radians at |x| ~ 100
+            m.fourier_coefficients.requires_grad_(prec != "f32")      # the fp32 kernels take them as constants
+        with torch.no_grad():
+            m.output_linear[0].weight.mul_(4.0)
+            m.output_linear[0].bias.fill_(-5.0)
+        return m
+
+    m32 = model("f32")
+    out = render_projection(m32, poses, W, W, 13.0 * W, S, 1400.0, 1600.0)
+    (((out.rgb_map - tgt) ** 2).sum() / (W * W)).backward()
+    ref = {k: p.grad.double() for k, p in m32.named_parameters() if p.grad is not None}
+    pix32 = out.rgb_map.detach()
+    del m32, out
+    m = model("f16s8")
+    _, pix = train_step_mse(m, projection_spec(poses, W, W, 13.0 * W, S, 1400.0, 1600.0), tgt)
+    assert rel_l2(pix.cpu().numpy(), pix32.cpu().numpy()) < 1e-4
+    got = {k: p.grad.double() for k, p in m.named_parameters() if p.grad is not None}
+    tot = float(torch.sqrt(sum(((got[k] - ref[k]) ** 2).sum() for k in ref)) / torch.sqrt(sum((ref[k] ** 2).sum() for k in ref)))
+    assert tot < TOL["f16s8"]["grad"], tot
+    for k in ref:
+        assert float((got[k] - ref[k]).norm() / ref[k].norm()) < 2 * TOL["f16s8"]["grad"], k
+    if enc == "fourier":
+        g = m.fourier_coefficients.grad
+        assert g is not None and bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0
+
+
 def test_full_size_projection_properties():
     """BASELINE size C4 (512x512 rays x 128 samples, 8x256) at the TRAINING precision (f16), with no CPU oracle in reach:
     the f16 pixels against the exact-fp32 MFMA path on every pixel (relative L2 <= 1e-4 - the north-star bar - and max
