@@ -660,9 +660,15 @@ def test_full_size_encoded_gradients(enc):
     assert tot < TOL["f16s8"]["grad"], tot
     for k in ref:
         assert float((got[k] - ref[k]).norm() / ref[k].norm()) < 2 * TOL["f16s8"]["grad"], k
-    if enc == "fourier":
+    if enc == "fourier":      # the coefficient gradient: 8-bit path (k_wgrad_s8 row) against the 16-bit path (k_wgrad_bf16 row)
         g = m.fourier_coefficients.grad
         assert g is not None and bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0
+        g8 = g.double().clone()
+        del m
+        m16 = model("f16")
+        train_step_mse(m16, projection_spec(poses, W, W, 13.0 * W, S, 1400.0, 1600.0), tgt)
+        g16 = m16.fourier_coefficients.grad.double()
+        assert float((g8 - g16).norm() / g16.norm()) < 2 * TOL["f16s8"]["grad"]
 
 
 def test_full_size_projection_properties():
