@@ -727,8 +727,8 @@ def test_full_size_projection_properties():
         assert rel_l2(g2[k], g1[k]) < 1e-5, k
 
 
-@pytest.mark.parametrize("prec", ["f16", "f16s8", "bf16"])
-def test_production_build_is_bit_identical_to_the_safe_waits_build(prec):
+@pytest.mark.parametrize("prec,enc", [("f16", "none"), ("f16s8", "none"), ("bf16", "none"), ("f16s8", "barf"), ("f16", "barf")])
+def test_production_build_is_bit_identical_to_the_safe_waits_build(prec, enc):
     """Race detector for the hand-counted s_waitcnt vmcnt / lgkmcnt protocol of the chain kernels: libafx_safe.so is the
     same source with every counted wait replaced by a full one (-DAFX_SAFE_WAITS).  A deterministic under-wait would
     survive a run-to-run comparison; it cannot survive this one.  512x512 x 128, 8x256: pixels and every gradient."""
@@ -744,8 +744,14 @@ def test_production_build_is_bit_identical_to_the_safe_waits_build(prec):
     spec = projection_spec(poses, W, W, 13.0 * W, 128, 1400.0, 1600.0)
     res = []
     for variant in ("", "safe"):
-        m = _bench_model(prec)
-        m._engine = Engine(256, 8, "none", 0, variant=variant)
+        torch.manual_seed(0)
+        m = make_model(8, 256, enc, precision=prec)
+        with torch.no_grad():
+            m.output_linear[0].weight.mul_(4.0)
+            m.output_linear[0].bias.fill_(-5.0)
+        if enc == "barf":
+            m.update_barf_alpha(2.5, "pts")
+        m._engine = Engine(256, 8, enc, 5 if enc != "none" else 0, variant=variant)
         with torch.no_grad():
             fwd = render_projection(m, poses, W, W, 13.0 * W, 128, 1400.0, 1600.0).rgb_map
         loss, pix = train_step_mse(m, spec, tgt)
