@@ -406,8 +406,8 @@ def usable_cpus():
 
 def dp_parity(model, rank, world, pose, target, W, H, focal, S, near, far, train_step_mse, projection_spec, afx_dist):
     """N ranks take contiguous shards of ONE global batch (the rays of one projection), all-reduce; rank 0 also
-    computes that batch alone: relative L2 between the two flat gradients.  Differences: fp32 summation order and, with the 8-bit
-    stash, the stochastic rounding of dZ', whose random bits are hashed from a sample's position inside its launch (~1e-5)."""
+    computes that batch alone: relative L2 between the two flat gradients (fp32 summation order is the only difference: the stash's
+    stochastic rounding is seeded by the sample's position in space, not by its place in a launch)."""
     n = W * H
     start, count = afx_dist.shard(n, rank, world)
     dist.broadcast(target, 0)
