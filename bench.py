@@ -133,6 +133,29 @@ def live_traffic(args):
         "live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE child passes of this command (FETCH_SIZE x2 per MI355X_MICROARCH.md)"
 
 
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` outside torchrun: start `python -m torch.distributed.run ... bench.py <same flags>` as a CHILD
+    process (one rank per GPU) and return its exit code.  This process never touches the GPU (a process that has initialised it
+    must not exec another program on this pool, and a parent holding the device would count against the card's process limit);
+    the child's stdout - rank 0's one JSON line - and stderr are inherited, i.e. relayed as they are."""
+    import signal, socket, subprocess
+    with socket.socket() as s:          # a free rendezvous port on the loop-back interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    pr = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        return pr.wait()
+    except KeyboardInterrupt:
+        os.killpg(pr.pid, signal.SIGTERM)      # exactly the process group this call started
+        return pr.wait()
+
+
+DP_PARITY_BAR = 1e-5      # all-reduced N-rank gradient vs the 1-rank gradient of the same global batch (fp32 summation order only)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,6 +177,9 @@ def main():
                     help="skip the live rocprofv3 --pmc passes for roofline.traffic (use the committed profile instead); "
                          "required when this command itself runs under rocprofv3")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
 
     live = (None, "not measured")
     # (device_count() does not initialise the GPU on this image)
@@ -337,6 +363,19 @@ def main():
         if fused:
             result.update(dp_parity(model, rank, world, poses[0], targets[0], W, H, focal, S, near, far, train_step_mse,
                                     projection_spec, afx_dist))
+            # a data-parallel line is only reported when the collective really ran over all N ranks and reproduced the 1-rank gradient
+            bad = None
+            if result["rccl_ranks"] != args.gpus:
+                bad = f"process group has {result['rccl_ranks']} ranks, --gpus {args.gpus}"
+            elif rank == 0 and not result["dp_grad_parity"] <= DP_PARITY_BAR:
+                bad = f"dp_grad_parity {result['dp_grad_parity']:.3e} > {DP_PARITY_BAR:g}"
+            flag = torch.tensor([1.0 if bad else 0.0], device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if float(flag.item()) > 0:
+                if rank == 0:
+                    print(json.dumps(result), file=sys.stderr, flush=True)
+                dist.destroy_process_group()
+                raise SystemExit(f"DATA-PARALLEL FAILURE: {bad or 'see rank 0'}")
     trained_state = {k: v.detach().clone() for k, v in model.state_dict().items()}
     if rank == 0 and world == 1 and fused and not args.no_grad_check:
         # Full-size gradient check of the timed configuration (same workspace, same chunking): the fused step's weight gradient of

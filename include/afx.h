@@ -48,6 +48,11 @@ enum { AFX_ENC_NONE = 0, AFX_ENC_BARF = 1, AFX_ENC_FOURIER = 2 };
  *            Backward: the input-gradient chain runs normalised by dL/draw
  *            (no loss scaling needed), the weight-gradient contraction carries
  *            a power-of-two scale taken from the batch's largest |dL/draw|.
+ *            RANGE: f16 holds |x| <= 65504 - a hidden activation beyond that becomes inf and the pixel NaN (the
+ *            conversion is v_cvt_pk_f16_f32, round-to-nearest, no saturation: a clamp would cost two VALU
+ *            instructions per packed pair in the hottest epilogue).  With nn.Linear-initialised weights and world
+ *            coordinates of +-100 the activations of an 8x256 model stay below ~1e2; a model that can exceed the
+ *            range belongs on BF16 / BF16X3 (fp32 exponent range).  The training driver stops on a non-finite loss.
  *   F16S8  : F16 arithmetic; the backward pass keeps its per-sample stash
  *            (H_l, and the normalised chain J_l) as bf8 (e5m2) instead of f16:
  *            half the HBM round trip that bounds a training step.  Forward
@@ -236,8 +241,14 @@ int afx_grid_update(const afx_grid_desc* grid, float* occs, float* occs_scratch,
 int afx_grid_binarize(const afx_grid_desc* grid, const float* occs, float occ_thre, uint8_t* binary, uint32_t* bits,
                       double* partial_ws, void* stream);
 
+/* Restoring a trained grid: the reference assigns `acc_grid._binary = grid_occupancy` (visualization/visualization.py:162)
+ * before query_occ / acc_ray_marching.  Packs a caller-supplied byte mask binary[n_cells] (non-zero = occupied) into the
+ * bitfield the march reads. */
+int afx_grid_pack(const afx_grid_desc* grid, const uint8_t* binary, uint32_t* bits, void* stream);
+
 /* nerfacc.ray_marching: t range = ray / scene_aabb intersection clipped to [near, far]; fixed-step lattice
- * t_min + k*step; a step is kept when the cell holding its mid-point is occupied (grid_bits NULL: every step). */
+ * t_min + k*step; a step belongs to the ray while its mid-point lies before t_max (nerfacc marches `while (t_mid < far)`) and
+ * is kept when the cell holding its mid-point is occupied (grid_bits NULL: every step). */
 typedef struct afx_march_args {
   const float* origins;         /* [R,3] */
   const float* dirs;            /* [R,3] */

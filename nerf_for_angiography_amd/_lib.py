@@ -77,6 +77,7 @@ _SIGS = {
     "afx_grid_points": (C.c_int, [C.POINTER(GridDesc), C.c_void_p, C.c_int64, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
     "afx_grid_update": (C.c_int, [C.POINTER(GridDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_float, C.c_void_p]),
     "afx_grid_binarize": (C.c_int, [C.POINTER(GridDesc), C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "afx_grid_pack": (C.c_int, [C.POINTER(GridDesc), C.c_void_p, C.c_void_p, C.c_void_p]),
     "afx_march_count": (C.c_int, [C.POINTER(MarchArgs), C.c_void_p, C.c_void_p]),
     "afx_march_write": (C.c_int, [C.POINTER(MarchArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "afx_march_visibility": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,

@@ -858,6 +858,15 @@ extern "C" int afx_grid_binarize(const afx_grid_desc* grid, const float* occs, f
   return AFX_OK;
 }
 
+extern "C" int afx_grid_pack(const afx_grid_desc* grid, const uint8_t* binary, uint32_t* bits, void* stream) {
+  int64_t nc;
+  if (int rc = check_grid(grid, "afx_grid_pack", &nc)) return rc;
+  if (!binary || !bits) return fail(AFX_E_INVALID, "afx_grid_pack: null argument");
+  hipLaunchKernelGGL(k_grid_pack, blocks_for((nc + 31) / 32), dim3(256), 0, (hipStream_t)stream, binary, nc, bits);
+  HIPCHK(hipGetLastError());
+  return AFX_OK;
+}
+
 static int fill_march(const afx_march_args* m, MarchArgs& a, const char* who) {
   if (!m) return fail(AFX_E_INVALID, "%s: null args", who);
   if (m->n_rays < 0) return fail(AFX_E_INVALID, "%s: n_rays < 0", who);

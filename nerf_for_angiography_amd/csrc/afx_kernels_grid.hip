@@ -130,6 +130,19 @@ __global__ void k_grid_binarize(const float* occs, int64_t n, const double* part
   bits[w] = word;
 }
 
+// bitfield of a byte mask that did not come out of k_grid_binarize (a restored grid): bits[w] bit b = binary[32 w + b] != 0
+__global__ void k_grid_pack(const uint8_t* binary, int64_t n, uint32_t* bits) {
+  const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w * 32 >= n) return;
+  uint32_t word = 0;
+  for (int b = 0; b < 32; ++b) {
+    const int64_t c = w * 32 + b;
+    if (c >= n) break;
+    word |= (binary[c] ? 1u : 0u) << b;
+  }
+  bits[w] = word;
+}
+
 // --- ray marching (nerfacc.ray_marching, fixed-step lattice, AABB contraction) ----------------------------------------
 struct MarchArgs {
   const float* org; const float* dir;      // [R,3]
@@ -163,6 +176,13 @@ __device__ __forceinline__ void march_range(const MarchArgs& a, int64_t r, float
   float ns = ceilf(__fdiv_rn(__fsub_rn(t_max, t_min), a.dt));
   if (!(ns > 0.f)) ns = 0.f;
   n_steps = t_min >= 1e10f ? 0 : (ns > 2.0e9f ? 2000000000 : (int)ns);
+  // nerfacc marches `while (t_mid < far)`: a step belongs to the ray when its MID-POINT lies before t_max (not its start), so the
+  // ceil() above is corrected by the step(s) at the end whose mid-point falls outside / inside - same fp32 expressions as the loops below
+  auto mid_of = [&](int k) { const float ts = __fadd_rn(t_min, __fmul_rn((float)k, a.dt)); return __fmul_rn(__fadd_rn(ts, __fadd_rn(ts, a.dt)), 0.5f); };
+  if (n_steps < 2000000000) {
+    while (n_steps > 0 && !(mid_of(n_steps - 1) < t_max)) --n_steps;
+    for (int i = 0; i < 2 && t_min < 1e10f && mid_of(n_steps) < t_max; ++i) ++n_steps;
+  }
   tmin = t_min;
 }
 __device__ __forceinline__ bool march_keep(const MarchArgs& a, const float o[3], const float d[3], float ts, float te) {

@@ -48,17 +48,22 @@ def broadcast_parameters(model, src: int = 0):
 
 
 class GradSync:
-    """SUM the flat parameter gradient over ranks with one all-reduce (no division).
+    """SUM the flat parameter gradient over ranks with one all-reduce.
 
     Contract (one, everywhere): the loss of a step is the mean over the GLOBAL ray batch, so every rank seeds its
-    backward with dL/dpixel = 2 (pixel - target) / n_global - `render.train_step_mse(..., n_global=...)` bakes
-    1/n_global into the kernel, the autograd path divides the summed squared error by n_global - and the per-rank
-    gradients ADD UP to the single-GPU gradient of the union batch.  That is exact for unequal shards too (a mean of
-    per-rank means is not).  `seconds` accumulates nothing on the host: time the collective with events around it."""
+    backward with dL/dpixel = 2 (pixel - target) / n_global and the per-rank gradients ADD UP to the single-GPU gradient
+    of the union batch.  That is exact for unequal shards too (a mean of per-rank means is not).
+      * `render.train_step_mse(model, spec, target)` with this hook installed and no `n_global` derives it itself: one
+        all-reduce of the rank's ray count (`global_count`), so the default call is correct on any number of ranks;
+      * the autograd path (`render_*` -> your loss -> `.backward()`) must divide by the global count as well:
+        `dist.global_mse(pred, target)` does; a loss that is a LOCAL mean (`F.mse_loss(pred, target)`) needs
+        `GradSync(local_mean=True)`, which averages instead of summing (exact for equal shards only - the reason the
+        global-count form is the default)."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, local_mean: bool = False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.local_mean = bool(local_mean)
         self.on_call = None            # optional (before, after) hooks, e.g. event records for bench.py
 
     def __call__(self, flat_grad: torch.Tensor):
@@ -66,8 +71,18 @@ class GradSync:
             if self.on_call is not None:
                 self.on_call[0]()
             dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+            if self.local_mean:
+                flat_grad.div_(self.world)
             if self.on_call is not None:
                 self.on_call[1]()
+
+    def global_count(self, n_local: int, device) -> int:
+        """Rays of this step over all ranks (one tiny all-reduce; the ranks' batches may differ in size)."""
+        if self.world == 1:
+            return int(n_local)
+        t = torch.tensor([int(n_local)], dtype=torch.int64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return int(t.item())
 
     def install(self):
         _render._grad_hook = self
@@ -76,6 +91,18 @@ class GradSync:
     @staticmethod
     def uninstall():
         _render._grad_hook = None
+
+
+def global_mse(pred: torch.Tensor, target: torch.Tensor, group=None) -> torch.Tensor:
+    """sum_r (pred_r - target_r)^2 / n_global: the loss whose per-rank gradients a SUM all-reduce (GradSync) turns into the
+    gradient of the mean over the union batch (nerf/run_nerf_acc.py:298 on one device).  The returned value is this rank's
+    SHARE of the global loss (add the ranks' values for logging)."""
+    n = pred.numel()
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        t = torch.tensor([n], dtype=torch.int64, device=pred.device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        n = int(t.item())
+    return ((pred - target) ** 2).sum() / n
 
 
 def density_grid_sharded(model, outside: float, n: int, group=None) -> torch.Tensor:

@@ -421,6 +421,15 @@ def grid_binarize(roi_aabb, resolution, occs, occ_thre, binary_u8, bits, partial
                                      Engine._stream(occs.device)), "afx_grid_binarize")
 
 
+def grid_pack(roi_aabb, resolution, binary_u8, bits):
+    """afx_grid_pack: the march's bitfield from a byte mask (a restored grid)."""
+    lib = _lib.load()
+    if binary_u8.device.type != "cuda":
+        raise AfxError("grid_pack: the occupancy grid lives on a GPU; there is no CPU fallback")
+    g = _grid_desc(roi_aabb, resolution)
+    _lib.check(lib.afx_grid_pack(C.byref(g), _ptr(binary_u8), _ptr(bits), Engine._stream(binary_u8.device)), "afx_grid_pack")
+
+
 def march(origins, dirs, scene_aabb, near_plane, far_plane, step, grid_bits=None, grid_aabb=None, grid_res=None, want_points=True):
     """Grid-skipping fixed-step march -> packed (ray_indices int32 [n], t_starts [n], t_ends [n], mid-points [n,3] | None,
     offsets int64 [R+1])."""

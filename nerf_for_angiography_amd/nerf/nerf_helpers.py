@@ -57,18 +57,48 @@ def get_ray_entropy(sigmas, rgb_map, threshold=0.4):
     return entropy * ((1 - rgb_map) > threshold).detach()
 
 
+def _render_volume_density_ops(radiance_field, ray_directions, depth_values):
+    """The two branches of nerf/nerf_helpers.py:59-123 the reference's training path never takes, on PyTorch-ROCm operators
+    (same device; kept for capability, not accelerated):
+      C == 2 (:67-83): emission-absorption - density relu(last channel), colour sigmoid(first), opacity 1 - exp(-sigma dz)
+        with the PLAIN depth differences (no ||d||), weights = opacity * exclusive transmittance, entropy of the opacity
+        profile averaged over the rays whose opacities add up to more than 0.7 (a scalar);
+      C  > 2 (:86-87): density relu(mean over channels), then the one-channel absorption formulas (||d||-scaled steps,
+        rgb_map = prod exp(-sigma dz), depth_map = sum(alpha z), per-ray entropy masked at 1 - rgb_map > 0.4)."""
+    z = depth_values
+    step = torch.cat((z[..., 1:] - z[..., :-1], torch.full_like(z[..., :1], 1e10)), dim=-1)
+    if radiance_field.shape[-1] == 2:
+        sigma_a, rgb = torch.relu(radiance_field[..., 1]), torch.sigmoid(radiance_field[..., :1])
+        opacity = 1.0 - torch.exp(-sigma_a * step)
+        weights = opacity * cumprod_exclusive(1.0 - opacity + 1e-10)
+        rgb_map = (weights.unsqueeze(-1) * rgb).sum(dim=-2).squeeze()
+        depth_map = (weights * z).sum(dim=-1)
+        total = opacity.sum(dim=-1)
+        p = opacity / (total.unsqueeze(-1) + 1e-10)
+        per_ray = -(p * torch.log(p + 1e-10)).sum(dim=-1) * (total > 0.7).detach()
+        return rgb_map, depth_map, weights, per_ray.mean(), [sigma_a, rgb]
+    sigma_a = torch.relu(radiance_field.mean(dim=-1))
+    trans = torch.exp(-sigma_a * (step * ray_directions.norm(dim=-1, keepdim=True)))
+    weights = (1.0 - trans + 1e-10) * cumprod_exclusive(trans)
+    rgb_map = trans.prod(dim=-1)
+    depth_map = (trans * z).sum(dim=-1)
+    rgb = torch.ones(*sigma_a.shape[:2], 1, device=sigma_a.device)
+    return rgb_map, depth_map, weights, get_ray_entropy(sigma_a, rgb_map), [sigma_a, rgb]
+
+
 def render_volume_density(radiance_field, ray_directions, depth_values, raw_noise_std=0.):
-    """nerf/nerf_helpers.py:59-123 -> (rgb_map, depth_map, weights, entropy, [sigma_a, rgb]) for the configuration the
-    reference trains: ONE output channel (sigmoid density, absorption only), on the GPU (afx_composite_dense; the gradient
-    flows through rgb_map, the quantity the loss uses; depth_map / weights / entropy are returned detached).  The
-    reference's quirks are kept in the kernel: last distance 1e10 (D3), ||d|| scaling (D4), depth_map = sum(alpha*z) (D5).
-    The emission-absorption (2-channel) and mean-relu (>2) branches of the reference are not part of its training path
-    and are not provided; host tensors are refused - there is no CPU fallback (tests compare with oracle/)."""
-    if radiance_field.shape[-1] != 1:
-        raise NotImplementedError("render_volume_density: one output channel (num_output_channels = 1) is what the reference trains")
+    """nerf/nerf_helpers.py:59-123 -> (rgb_map, depth_map, weights, entropy, [sigma_a, rgb]).  The configuration the reference
+    trains - ONE output channel (sigmoid density, absorption only) - runs in the HIP library (afx_composite_dense; the gradient
+    flows through rgb_map, the quantity the loss uses; depth_map / weights / entropy are returned detached).  The reference's
+    quirks are kept in the kernel: last distance 1e10 (D3), ||d|| scaling (D4), depth_map = sum(alpha*z) (D5).  The
+    emission-absorption (2-channel) and mean-relu (> 2) branches, which the reference's training path never takes, run on
+    PyTorch-ROCm operators (same device, not accelerated).  Host tensors are refused - there is no CPU fallback (tests
+    compare with oracle/)."""
     if not radiance_field.is_cuda:
         from .._lib import AfxError
         raise AfxError("render_volume_density: tensors must live on the GPU; there is no CPU fallback")
+    if radiance_field.shape[-1] != 1:
+        return _render_volume_density_ops(radiance_field.float(), ray_directions.float(), depth_values.float())
     raw = radiance_field[..., 0].float().contiguous()
     rgb_map, depth_map, weights, entropy, sigma_a = _CompositeDenseFn.apply(raw, ray_directions.float().contiguous(),
                                                                              depth_values.float().contiguous())
@@ -138,6 +168,13 @@ def fine_sampling(depth_values, weights_coarse, ray_origins, ray_directions, coa
     if u is None:
         u = torch.rand(n_rays, depth_samples_per_ray_fine, device=weights_coarse.device)
     depth_vals = _engine.fine_depths(depth_values.float().contiguous(), weights_coarse.detach().float().contiguous(), u)
+    if not getattr(network, "fused", False):
+        # configurations outside the fused kernels (tanh / sine / skip block / several channels): the reference's own sequence
+        # (:187-192) on the module's PyTorch-ROCm operators - points, chunked predictions, dense compositing
+        pts = ray_origins[..., None, :] + ray_directions[..., None, :] * depth_vals[..., :, None]
+        raw = get_predictions(network, pts.reshape(-1, 3), chunksize).reshape(n_rays, depth_vals.shape[-1], -1)
+        rgb_map, depth_map, _, entropy, _ = render_volume_density(raw, ray_directions, depth_vals)
+        return rgb_map, depth_map, entropy
     out = render_rays(network, ray_origins, ray_directions, mode="dense", z=depth_vals, want_aux=True)
     return out.rgb_map, out.depth_map, out.entropy
 

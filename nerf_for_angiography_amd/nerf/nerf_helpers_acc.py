@@ -62,10 +62,8 @@ def acc_render_volume_density(predictions, ray_indices, t_starts, t_ends, n_rays
         pred = pred.clone()
         pred[zero_idx] = -float("inf")
     if not pred.is_cuda:
-        sig = torch.sigmoid(pred)
-        alphas = torch.exp(-sig * (t_ends - t_starts).reshape(-1))
-        out = torch.ones(n_rays, dtype=alphas.dtype).index_reduce(0, ray_indices.long(), alphas, "prod")
-        return out.float(), None
+        from .._lib import AfxError
+        raise AfxError("acc_render_volume_density: tensors must live on the GPU; there is no CPU fallback (tests compare with oracle/)")
     rgb = _PackedFn.apply(pred.contiguous(), ray_indices.to(torch.int32).contiguous(),
                           t_starts.reshape(-1).float().contiguous(), t_ends.reshape(-1).float().contiguous(), int(n_rays))
     return rgb, None

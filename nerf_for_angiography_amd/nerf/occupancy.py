@@ -35,6 +35,7 @@ class ContractionType:
 
 class OccupancyGrid(torch.nn.Module):
     NUM_DIM = 3
+    JITTER_STREAM_TAG = 0x47524944 << 32          # Philox stream ids of the in-cell jitter: tag | training step
 
     def __init__(self, roi_aabb, resolution=128, contraction_type=ContractionType.AABB, seed: int = 0):
         super().__init__()
@@ -62,8 +63,43 @@ class OccupancyGrid(torch.nn.Module):
     def binary(self):
         return self._binary_u8.view(*self._res_host).bool()
 
+    @binary.setter
+    def binary(self, mask):
+        self.set_binary(mask)
+
+    # the reference restores a trained grid with `acc_grid._binary = grid_occupancy` (visualization/visualization.py:162,
+    # nerfacc 0.3.x keeps the mask in `_binary`): the same assignment works here and reaches the bitfield the march reads
+    @property
+    def _binary(self):
+        return self.binary
+
+    @_binary.setter
+    def _binary(self, mask):
+        self.set_binary(mask)
+
+    @torch.no_grad()
+    def set_binary(self, mask):
+        """Install an occupancy mask [res,res,res] (or flat [num_cells]; bool or 0/1 numbers): the byte tensor `binary` views, and,
+        once the grid lives on the GPU, the packed bitfield of the march (afx_grid_pack).  `occs` is left alone."""
+        mask = torch.as_tensor(mask)
+        if mask.numel() != self.num_cells:
+            raise ValueError(f"binary: {mask.numel()} cells, expected {self.num_cells} = {self._res_host}")
+        self._binary_u8.copy_((mask.reshape(-1) != 0).to(torch.uint8))
+        self._bits_stale = not self._binary_u8.is_cuda      # a host-side grid is packed when it reaches the GPU
+        if self._binary_u8.is_cuda:
+            _engine.grid_pack(self._aabb_host, self._res_host, self._binary_u8, self._bits)
+
+    def _apply(self, fn, *args, **kwargs):
+        super()._apply(fn, *args, **kwargs)
+        if getattr(self, "_bits_stale", False) and self._binary_u8.is_cuda:
+            _engine.grid_pack(self._aabb_host, self._res_host, self._binary_u8, self._bits)
+            self._bits_stale = False
+        return self
+
     @property
     def bits(self):
+        if getattr(self, "_bits_stale", False):
+            raise AfxError("OccupancyGrid: the mask was set on the host; move the grid to the GPU (.to(device)) before marching")
         return self._bits
 
     def _require_gpu(self):
@@ -86,8 +122,9 @@ class OccupancyGrid(torch.nn.Module):
         else:
             indices = self._sample_uniform_and_occupied_cells(self.num_cells // 4).to(torch.int32).contiguous()
             n = indices.numel()
-        x = _engine.grid_points(self._aabb_host, self._res_host, indices, n, jitter=jitter, seed=self.seed, stream_id=int(step),
-                                device=self.occs.device)
+        # (stream tag "GRID" in the high word: the ray sampler draws from (seed, step) with the same seed, nerf/run_nerf_acc.py)
+        x = _engine.grid_points(self._aabb_host, self._res_host, indices, n, jitter=jitter, seed=self.seed,
+                                stream_id=self.JITTER_STREAM_TAG | int(step), device=self.occs.device)
         occ = occ_eval_fn(x).reshape(-1).float().contiguous()
         _engine.grid_update(self._aabb_host, self._res_host, self.occs, indices, occ, ema_decay, self._scratch)
         _engine.grid_binarize(self._aabb_host, self._res_host, self.occs, occ_thre, self._binary_u8, self._bits, self._partial)

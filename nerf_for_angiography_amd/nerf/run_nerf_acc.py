@@ -145,9 +145,12 @@ def main(argv=None):
     tab_w = torch.from_numpy(train_ray_df['distance_pixel_value'].to_numpy()).float().to(device)
 
     # occupancy grid of the reference loop (run_nerf_acc.py:196-198); thresholds :68-70
-    early_stop_eps, alpha_thre = 1e-2, 1e-3
+    early_stop_eps, alpha_thre, vessel_alpha_thre = 1e-2, 1e-4, 5e-2
     scene_aabb = torch.tensor([-outside, -outside, -outside, outside, outside, outside], dtype=torch.float32, device=device)
     acc_grid = OccupancyGrid(roi_aabb=scene_aabb, resolution=128, contraction_type=ContractionType.AABB, seed=args.seed).to(device) \
+        if args.march == 'grid' else None
+    # the reference's second grid (:198,286): same updates at the vessel threshold; it only feeds the exported occupancy volumes (:362-367)
+    vessel_acc_grid = OccupancyGrid(roi_aabb=scene_aabb, resolution=128, contraction_type=ContractionType.AABB, seed=args.seed + 1).to(device) \
         if args.march == 'grid' else None
     batch_size = 131072
 
@@ -173,7 +176,9 @@ def main(argv=None):
             # the reference's iteration body, run_nerf_acc.py:284-306
             with torch.no_grad():
                 acc_grid.train()
+                vessel_acc_grid.train()
                 acc_grid = acc_update_n_step(acc_grid, coarse_model, n_iter, occ_thre=alpha_thre)
+                vessel_acc_grid = acc_update_n_step(vessel_acc_grid, coarse_model, n_iter, occ_thre=vessel_alpha_thre)
                 ray_indices, t_starts, t_ends = acc_ray_marching(coarse_model, acc_grid, scene_aabb, batch_origins, batch_directions,
                                                                  depth_samples_per_ray_coarse, near_thresh, far_thresh,
                                                                  early_stop_eps, alpha_thre)
@@ -231,10 +236,17 @@ def main(argv=None):
             log.write(json.dumps(rec) + "\n")
             log.flush()
             print(rec, flush=True)
+            if not np.isfinite(rec['train_loss']):
+                raise FloatingPointError(
+                    f"non-finite training loss at iteration {n_iter} (precision {args.precision}): the f16 precisions hold hidden "
+                    "activations up to 65504 (include/afx.h); re-run with --precision bf16 (fp32 exponent range) or bf16x3")
             if psnr > highest_psnr:
                 highest_psnr, highest_iter = psnr, n_iter
                 coarse_model.save(os.path.join(args.log_dir, 'coarsemodel.pth'),
                                   {'epochs': n_iter, 'psnr': psnr, 'vessel_psnr': vessel_psnr})
+                if acc_grid is not None:      # the occupancy volumes the reference writes as VTK next to the best model (:362-367,384-385)
+                    np.save(os.path.join(args.log_dir, 'acc_grid_binary.npy'), acc_grid.binary.cpu().numpy())
+                    np.save(os.path.join(args.log_dir, 'vessel_acc_grid_binary.npy'), vessel_acc_grid.binary.cpu().numpy())
             if n_iter % save_every == 0 and n_iter > 0:
                 coarse_model.save(os.path.join(args.log_dir, f'coarsemodel-{n_iter}.pth'), {'epochs': n_iter})
             if n_iter - highest_iter > early_stop_iters:
@@ -242,7 +254,8 @@ def main(argv=None):
                 break
     log.close()
     return dict(history=history, best_psnr=highest_psnr, best_iter=highest_iter, model=coarse_model,
-                optimizer=coarse_optimizer, test_image=test_img, log_dir=args.log_dir)
+                optimizer=coarse_optimizer, test_image=test_img, log_dir=args.log_dir, acc_grid=acc_grid,
+                vessel_acc_grid=vessel_acc_grid)
 
 
 if __name__ == "__main__":

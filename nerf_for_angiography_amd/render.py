@@ -119,6 +119,21 @@ def _as_f32(t, device):
     return t.to(device=device, dtype=torch.float32)
 
 
+def _global_rays(n_local: int, n_global: Optional[int], device) -> int:
+    """The ray count the loss is the mean over.  An explicit n_global wins; with a multi-rank SUM gradient hook installed
+    (dist.GradSync) the ranks' counts are all-reduced, so that a default call is still the gradient of the GLOBAL mean; a
+    local-mean hook (GradSync(local_mean=True)) keeps the local count; a foreign multi-rank hook must be told."""
+    if n_global:
+        return int(n_global)
+    if _grad_hook is not None and getattr(_grad_hook, "world", 1) > 1:
+        if getattr(_grad_hook, "local_mean", False):
+            return int(n_local)
+        if hasattr(_grad_hook, "global_count"):
+            return _grad_hook.global_count(int(n_local), device)
+        raise AfxError("train_step_mse: a multi-rank gradient hook is installed; pass n_global (rays of the step over all ranks)")
+    return int(n_local)
+
+
 def train_step_mse(model, spec: RenderSpec, target: torch.Tensor, n_global: Optional[int] = None):
     """One fused training pass: render `spec`, L = mean over the (global) batch of (pixel - target)^2, backward.
 
@@ -126,11 +141,13 @@ def train_step_mse(model, spec: RenderSpec, target: torch.Tensor, n_global: Opti
     the gradients are ACCUMULATED into `.grad` of the model's Linear parameters exactly as loss.backward() would,
     so `optimizer.zero_grad(); train_step_mse(...); optimizer.step()` is the training iteration.  The forward pass
     is the backward kernel's own forward (f16 / bf16 operands), nothing is rendered twice.  Returns (loss, pixels), detached.
-    n_global: total rays of the step across all ranks (default: this batch) - the mean is over that count."""
+    n_global: total rays of the step across all ranks - the mean is over that count.  Default: this batch; with a
+    multi-rank gradient hook installed (dist.GradSync, a SUM all-reduce) the ranks' ray counts are all-reduced instead, so
+    the default call stays the gradient of the global mean."""
     _check_model(model)
     if model.precision == "f32":
         raise NotImplementedError("train_step_mse needs a 16-bit precision (f16, bf16, bf16x3); with 'f32' use render + autograd")
-    n = int(n_global) if n_global else int(spec.n_rays)
+    n = _global_rays(spec.n_rays, n_global, model.flat_params.device)
     flat_grad = torch.zeros(model.engine.param_count, dtype=torch.float32, device=model.flat_params.device)
     coef_grad = model._coef_grad_buffer()
     s_pad = (spec.n_samples + 31) // 32 * 32

@@ -546,7 +546,7 @@ def ray_aabb(o: Tensor, d: Tensor, aabb: Tensor):
 
 def march_grid(o: Tensor, d: Tensor, scene_aabb: Optional[Tensor], near: Optional[float], far: Optional[float], dt: float,
                binary: Optional[Tensor] = None, grid_aabb: Optional[Tensor] = None):
-    """Fixed-step lattice t_min + k dt over [t_min, t_max); a step is kept when the cell of its mid-point is occupied.
+    """Fixed-step lattice t_min + k dt, steps whose mid-point lies in [t_min, t_max); a step is kept when the cell of its mid-point is occupied.
     -> packed ray-sorted (ray_indices, t_starts, t_ends), plain Python loops (small cases only)."""
     n = o.shape[0]
     if scene_aabb is not None:
@@ -562,10 +562,14 @@ def march_grid(o: Tensor, d: Tensor, scene_aabb: Optional[Tensor], near: Optiona
     for r in range(n):
         if float(tmin[r]) >= 1e10:
             continue
-        ns = int(max(0.0, math.ceil(float((tmax[r] - tmin[r]) / dtf))))
+        # nerfacc 0.3.x marches `while (t_mid < far)`: a step is the ray's when its mid-point lies before t_max
+        ns = int(max(0.0, math.ceil(float((tmax[r] - tmin[r]) / dtf)))) + 2
         k = torch.arange(ns, dtype=torch.float32)
         s = tmin[r] + k * dtf
         e = s + dtf
+        inside_range = ((s + e) * 0.5) < tmax[r]
+        ns = int(inside_range.sum())                 # mid-points are monotone: a prefix
+        s, e = s[:ns], e[:ns]
         keep = torch.ones(ns, dtype=torch.bool)
         if binary is not None and ns > 0:
             mid = o[r][None, :] + d[r][None, :] * ((s + e) * 0.5)[:, None]

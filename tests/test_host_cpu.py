@@ -225,8 +225,19 @@ def test_nerf_helpers_host_paths_match_golden(golden):
     # one-channel configuration the reference trains
     with pytest.raises(AfxError, match="no CPU fallback"):
         nh.render_volume_density(T(g5["raw_n"]), T(g5["d"]), T(g5["z2"]))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(AfxError, match="no CPU fallback"):      # (2-channel / mean-relu branches: PyTorch-ROCm operators, GPU only)
         nh.render_volume_density(T(g5["raw_c2"]), T(g5["d"]), T(g5["z2"]))
+    # ... whose arithmetic is the reference's (G5 pins the 2-channel branch): the operator route, called directly on host tensors
+    from oracle import angio_oracle as orc
+    got = nh._render_volume_density_ops(T(g5["raw_c2"]), T(g5["d"]), T(g5["z2"]))
+    want = orc.render_volume_density(T(g5["raw_c2"]), T(g5["d"]), T(g5["z2"]))
+    for a, b in zip(got[:4], want[:4]):
+        assert rel_l2(a.numpy(), b.numpy()) < 1e-6
+    raw3 = torch.randn(6, 9, 3)
+    got = nh._render_volume_density_ops(raw3, T(g5["d"])[:6], T(g5["z2"])[:6, :9])
+    want = orc.render_volume_density(raw3, T(g5["d"])[:6], T(g5["z2"])[:6, :9])
+    for a, b in zip(got[:4], want[:4]):
+        assert rel_l2(a.numpy(), b.numpy()) < 1e-6
     with pytest.raises(AfxError, match="no CPU fallback"):
         nh.fine_sampling(torch.linspace(0, 1, 8), torch.rand(3, 8), torch.zeros(3, 3), torch.ones(3, 3), None, None, 4, 64)
 
@@ -238,10 +249,9 @@ def test_acc_helpers_host_paths():
     ri, ts, te = na.acc_ray_marching(None, None, None, o, d, 16, 1400.0, 1600.0)
     ri_o, ts_o, te_o = orc.march_uniform(1400.0, 1600.0, 16, 5)
     assert torch.equal(ri.long(), ri_o) and torch.equal(ts, ts_o) and torch.equal(te, te_o)
-    pred = torch.randn(80, 1)
-    pix, ent = na.acc_render_volume_density(pred, ri, ts, te, 5, 16)
-    assert ent is None
-    assert rel_l2(pix.numpy(), orc.acc_render_volume_density(pred, ri, ts, te, 5).numpy()) < 1e-6
+    from nerf_for_angiography_amd._lib import AfxError
+    with pytest.raises(AfxError, match="no CPU fallback"):
+        na.acc_render_volume_density(torch.randn(80, 1), ri, ts, te, 5, 16)
     assert na.acc_update_n_step(None, None, 0) is None
 
 
@@ -298,7 +308,46 @@ def test_occupancy_product_refuses_cpu():
     grid.eval()
     with pytest.raises(RuntimeError):
         grid.every_n_step(0, lambda x: x[:, :1])
+    # restoring a trained grid the reference's way (visualization/visualization.py:162): the assignment reaches the module's mask;
+    # the packed bitfield the march reads is made on the GPU, so a host-side grid refuses to hand out stale bits
+    mask = torch.zeros(8, 8, 8, dtype=torch.bool)
+    mask[2:5, 3, 1] = True
+    grid._binary = mask
+    assert torch.equal(grid.binary, mask) and torch.equal(grid._binary, mask)
+    assert grid.query_occ(torch.tensor([[-0.3, -0.2, -0.7], [0.9, 0.9, 0.9]])).tolist() == [True, False]
+    with pytest.raises(AfxError, match="move the grid to the GPU"):
+        grid.bits
+    with pytest.raises(ValueError):
+        grid.binary = torch.zeros(7)
     assert na.acc_update_n_step(None, None, 0) is None
+
+
+def test_bench_gpus_n_starts_torchrun_as_a_child(monkeypatch):
+    """`python bench.py --gpus N` outside torchrun: the parent only spawns `python -m torch.distributed.run ... bench.py <flags>`
+    (a child process, rendezvous on 127.0.0.1) and returns its exit code."""
+    sys.path.insert(0, ROOT)
+    import subprocess
+    import bench
+    seen = {}
+
+    class FakeProc:
+        pid = 0
+
+        def __init__(self, cmd, **kw):
+            seen["cmd"], seen["kw"] = cmd, kw
+
+        def wait(self):
+            return 7
+    monkeypatch.setattr(subprocess, "Popen", FakeProc)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    assert os.path.basename(cmd[-7]) == "bench.py" and seen["kw"]["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 
 
 def test_bench_flop_model():
@@ -324,11 +373,12 @@ def _dp_problem():
 def _dp_flat_grad(m, o, d, tgt, n_global):
     """Flat gradient of sum_r (pixel_r - target_r)^2 / n_global over the given rays, through the module's
     torch-operator path (CPU) and the reference's acc compositing - what a rank's fused kernels produce on a GPU."""
-    from nerf_for_angiography_amd.nerf.nerf_helpers_acc import acc_ray_marching, acc_render_volume_density
+    from nerf_for_angiography_amd.nerf.nerf_helpers_acc import acc_ray_marching
+    from oracle import angio_oracle as orc
     s = 16
     ri, ts, te = acc_ray_marching(m, None, None, o, d, s, 1400.0, 1600.0)
     pos = o[ri.long()] + d[ri.long()] * (ts + te) / 2.0
-    pix, _ = acc_render_volume_density(m(pos), ri, ts, te, o.shape[0], s)
+    pix = orc.acc_render_volume_density(m(pos), ri, ts, te, o.shape[0])
     loss = ((pix - tgt) ** 2).sum() / n_global
     m.zero_grad()
     loss.backward()
@@ -361,12 +411,24 @@ def _dp_worker(rank, world, port, q):
     render._grad_hook(g)                          # what _RenderFn.backward / train_step_mse call: SUM over ranks
     grid = afx_dist.density_grid_sharded(m, 100.0, 6)      # 7^3 = 343 points: unequal point ranges, one all-gather
     g_union = _dp_flat_grad(m, o, d, tgt, n) if rank == 0 else None      # the 1-rank gradient of the union batch
+    # the DEFAULT train_step_mse call (no n_global) under this hook: the ranks' ray counts are all-reduced (19 + 18 = 37)
+    n_default = render._global_rays(count, None, torch.device("cpu"))
+    # autograd path: dist.global_mse divides by the all-reduced count; a local-mean loss needs GradSync(local_mean=True)
+    gm = afx_dist.global_mse(tgt[start:start + count] * 0.5, tgt[start:start + count])
+    want_gm = float((((tgt[start:start + count] * 0.5) - tgt[start:start + count]) ** 2).sum() / n)
+    lm = afx_dist.GradSync(local_mean=True)
+    v = torch.full((4,), float(rank + 1))
+    lm(v)                                         # mean over ranks of (1, 2) = 1.5
+    render._grad_hook = lm
+    n_local_mean = render._global_rays(count, None, torch.device("cpu"))
+    render._grad_hook = sync
+    extra = (n_default, abs(float(gm) - want_gm) < 1e-7, v.tolist(), n_local_mean)
     with torch.no_grad():
         t = torch.linspace(-100.0, 100.0, 7, dtype=torch.float64).float()
         gy, gx, gz = torch.meshgrid(t, t, t, indexing="ij")
         want = torch.sigmoid(m(torch.stack([gx, gy, gz], -1).reshape(-1, 3))).reshape(7, 7, 7)
     q.put((rank, flat0[:8].tolist(), g.tolist(), None if g_union is None else g_union.tolist(), start, count,
-           bool(torch.allclose(grid, want, atol=1e-6))))
+           bool(torch.allclose(grid, want, atol=1e-6)), extra))
     afx_dist.GradSync.uninstall()
     dist.destroy_process_group()
 
@@ -385,7 +447,8 @@ def test_two_rank_gloo_grad_sync_and_sharding():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (r0, w0, g0, u0, s0, c0, d0), (r1, w1, g1, u1, s1, c1, d1) = res
+    (r0, w0, g0, u0, s0, c0, d0, x0), (r1, w1, g1, u1, s1, c1, d1, x1) = res
+    assert x0 == (37, True, [1.5] * 4, 19) and x1 == (37, True, [1.5] * 4, 18)      # default n_global / global_mse / local-mean mode
     assert d0 and d1                               # the sharded density grid equals the single-process grid on both ranks
     assert w0 == w1                                # rank 0's weights everywhere
     assert g0 == g1                                # identical synced gradients on both ranks
