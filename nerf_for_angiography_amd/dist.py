@@ -120,8 +120,17 @@ def density_grid_sharded(model, outside: float, n: int, group=None) -> torch.Ten
     idx = torch.arange(start, start + count, device=dev)
     i, j, k = idx // (m * m), (idx // m) % m, idx % m
     pts = torch.stack([t[j], t[i], t[k]], -1).contiguous()
-    with torch.no_grad():
-        sig = torch.sigmoid(model(pts)).reshape(-1) if count > 0 else torch.zeros(0, device=dev)
+    # (evaluated at render.grid_precision: the training precisions miss the grid's 1e-4 bar, see render.density_grid)
+    fused_gpu = getattr(model, "fused", False) and dev.type == "cuda"
+    keep = getattr(model, "precision", None)
+    if fused_gpu:
+        model.precision = _render.grid_precision(model)
+    try:
+        with torch.no_grad():
+            sig = torch.sigmoid(model(pts)).reshape(-1) if count > 0 else torch.zeros(0, device=dev)
+    finally:
+        if fused_gpu:
+            model.precision = keep
     if world == 1:
         return sig.reshape(m, m, m)
     per = (total + world - 1) // world + 1                      # equal-size slots for the collective

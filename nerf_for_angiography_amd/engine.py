@@ -513,7 +513,16 @@ def sample_rays(origins, dirs, pixels, weights, k, u=None, seed=0, stream_id=0):
     dev = origins.device
     if dev.type != "cuda":
         raise AfxError("sample_rays: the ray table must live on a GPU; there is no CPU fallback")
+    # (row-major [n,3] tables: a frame's `df[[x, y, z]].to_numpy()` is usually column-major, and .float().to(device) keeps those strides)
+    origins, dirs, weights = _f32(origins, "origins", dev), _f32(dirs, "dirs", dev), _f32(weights, "weights", dev)
+    if pixels is not None:
+        pixels = _f32(pixels, "pixels", dev)
+    if u is not None:
+        u = _f32(u, "u", dev)
     n = origins.shape[0]
+    if tuple(origins.shape) != (n, 3) or tuple(dirs.shape) != (n, 3) or weights.numel() != n or (pixels is not None and pixels.numel() != n) \
+            or (u is not None and u.numel() != n):
+        raise ValueError("sample_rays: expected origins/dirs [n,3], pixels/weights/u [n]")
     keys = torch.empty(n, device=dev)
     st = Engine._stream(dev)
     _lib.check(lib.afx_sample_keys(_ptr(weights), n, _ptr(u), int(seed), int(stream_id), _ptr(keys), st), "afx_sample_keys")

@@ -102,7 +102,8 @@ def main(argv=None):
     # held-out projection = last one (run_nerf_acc.py:85-99); [W,H] image indexing as upstream
     test_proj_id = proj_df.index[-1]
     test_ray_df = ray_df[ray_df['image_id'] == test_proj_id].copy()
-    cols = lambda df, stem: torch.from_numpy(df[[f'{stem}_x', f'{stem}_y', f'{stem}_z']].to_numpy()).float().to(device)
+    # (np.ascontiguousarray: a frame's multi-column to_numpy() is column-major, and .float().to(device) would keep those strides)
+    cols = lambda df, stem: torch.from_numpy(np.ascontiguousarray(df[[f'{stem}_x', f'{stem}_y', f'{stem}_z']].to_numpy(), dtype=np.float32)).to(device)
     test_origins, test_directions = cols(test_ray_df, 'ray_origins'), cols(test_ray_df, 'ray_directions')
     test_x = torch.from_numpy(test_ray_df['x_position'].to_numpy().astype('int64')).to(device)
     test_y = torch.from_numpy(test_ray_df['y_position'].to_numpy().astype('int64')).to(device)

@@ -184,14 +184,31 @@ def projection_spec(poses, width, height, focal, depth_samples_per_ray, near_thr
                       t_near=float(near_thresh), t_far=float(far_thresh))
 
 
-def density_grid(model, outside: float, n: int) -> torch.Tensor:
+GRID_PRECISION = "bf16x3"      # default arithmetic of density_grid: split bf16 - fp32-grade (the grid's 1e-4 bar) at 1/3 of the f16 rate
+
+
+def grid_precision(model) -> str:
+    """Arithmetic of a density-grid evaluation: the model's own precision when it is a strict one (f32, bf16x3), else split bf16."""
+    return model.precision if model.precision in ("f32", "bf16x3") else GRID_PRECISION
+
+
+def density_grid(model, outside: float, n: int, precision: Optional[str] = None) -> torch.Tensor:
     """sigma on meshgrid(t,t,t), t = linspace(-outside, outside, n+1), numpy 'xy' indexing as upstream
-    (visualization/visualization.py:100-102,209-229): grid[i,j,k] = sigma(t[j], t[i], t[k])."""
+    (visualization/visualization.py:100-102,209-229): grid[i,j,k] = sigma(t[j], t[i], t[k]).
+
+    precision: arithmetic of the MLP evaluation.  Default: the model's precision if that is a strict one (f32, bf16x3),
+    otherwise GRID_PRECISION (split bf16) whatever the model trains at: the reconstructed grid is held to 1e-4 relative L2 against the reference's fp32 path, which the training
+    precisions miss (f16: ~1e-3 on sigmoid(raw), tests/test_gpu_round3.py) - pixels average that error over a ray, a
+    grid cell does not.  201^3 points take ~25 ms in split bf16."""
     _check_model(model)
     dev = model.flat_params.device
     t = torch.linspace(-outside, outside, n + 1, dtype=torch.float64, device=dev).float()
     gy, gx, gz = torch.meshgrid(t, t, t, indexing="ij")      # [i,j,k] -> (x=t[j], y=t[i], z=t[k])
     pts = torch.stack([gx, gy, gz], -1).reshape(-1, 3).contiguous()
-    with torch.no_grad():
-        sig = model.engine.infer(model._prepared(), pts, model.precision, apply_sigmoid=True)
+    keep, model.precision = model.precision, (precision or grid_precision(model))
+    try:
+        with torch.no_grad():
+            sig = model.engine.infer(model._prepared(), pts, model.precision, apply_sigmoid=True)
+    finally:
+        model.precision = keep
     return sig.reshape(n + 1, n + 1, n + 1)

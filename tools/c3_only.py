@@ -45,6 +45,9 @@ def step3():
     rgb, dep, ent = fine_sampling(z, coarse.weights, o, d, m, None, NF, 131072)
     torch.nn.functional.mse_loss(rgb, tgt).backward(); opt.step()
 step3(); torch.cuda.synchronize()
+ws_ = m.engine._ws
+print(f"workspace: {ws_.numel() / 2**30:.2f} GiB at 0x{ws_.data_ptr():x} (offset in 2 MiB: {ws_.data_ptr() % (2 << 20)}, in 1 GiB: {ws_.data_ptr() % (1 << 30)}); "
+      f"torch reserved {torch.cuda.memory_reserved() / 2**30:.1f} GiB, allocated {torch.cuda.memory_allocated() / 2**30:.1f} GiB", flush=True)
 gr = torch.cat([p.grad.reshape(-1) for p in m.parameters() if p.grad is not None])
 print("after one step: grad |max|", float(gr.abs().max()), "NaNs", int(torch.isnan(gr).sum()), "weights |sum|", float(sum(p.double().abs().sum() for p in m.parameters())), flush=True)
 for rep in range(int(os.environ.get("REPS", "3"))):
