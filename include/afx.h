@@ -174,8 +174,14 @@ int afx_render_backward(afx_ctx* ctx, int prec, const void* prepared, const afx_
  * backward) without materialising anything between the steps: the backward kernel's forward recompute IS the
  * forward pass; it composites each ray in-kernel, forms dL/dpixel = 2 (pixel - target) * inv_n
  * (L = inv_n * sum_r (pixel_r - target_r)^2, inv_n = 1 / global ray count) and runs the gradient chain.
- * grad_flat += dL/dparams; args->pixel receives the rendered pixels.  16-bit precisions (BF16X3, BF16, F16) only; the padded
- * samples per ray must divide 256 (S <= 256) so that a ray never straddles a workgroup tile. */
+ * grad_flat += dL/dparams; args->pixel receives the rendered pixels.  16-bit precisions only.
+ * Rays whose padded sample count divides 256 lie inside one workgroup tile: ONE kernel per ray chunk.  Any other count (the
+ * reference's own 300 samples per ray, nerf/run_nerf_acc.py:129; the 128 + 64 of the hierarchical pass) is taken by
+ * AFX_PREC_F16S8 without an input encoding as the SAME work in two kernels per chunk - the forward half stashes H_l, the ReLU
+ * masks and g' = dt sigma (1 - sigma) per sample, a per-ray reduction forms pixel and dL/d(optical depth), the backward half
+ * runs the input-gradient chain from the masks - so nothing is computed twice; the workspace must then also hold
+ * n_rays * (1 + padded samples / 32) floats (AFX_Q_BWD_WORKSPACE_FULL with arg0 = n_rays, arg1 = n_samples includes them).
+ * Other precisions / encodings return AFX_E_INVALID for such counts (render, then afx_render_backward). */
 int afx_train_step_mse(afx_ctx* ctx, int prec, const void* prepared, const afx_render_args* args,
                        const float* target, float inv_n, float* grad_flat, void* stream);
 
@@ -207,6 +213,12 @@ int afx_composite_packed_backward(const float* pred, const int32_t* ray_indices,
  * z_coarse [S] (z_per_ray=0) or [R,S]; w_coarse[R,S]; z_out[R,S+n_fine]. */
 int afx_fine_depths(const float* z_coarse, int z_per_ray, const float* w_coarse, const float* u,
                     int64_t n_rays, int32_t n_coarse, int32_t n_fine, float* z_out, void* stream);
+
+/* The same from the coarse pass's per-sample optical depths tau[R,S] (afx_render_forward's `tau` output) instead of its weights:
+ * weights = (1 - alpha + 1e-10) * cumprod_exclusive(alpha), alpha = exp(-tau) (nerf/nerf_helpers.py:107-108) are formed per ray inside
+ * the kernel, so the coarse -> fine hand-over of the hierarchical step needs no [R,S] passes in between. */
+int afx_fine_depths_from_tau(const float* z_coarse, int z_per_ray, const float* tau_coarse, const float* u, int64_t n_rays,
+                             int32_t n_coarse, int32_t n_fine, float* z_out, void* stream);
 
 /* Ground-truth projector ray_tracing(interpolator, ...) — phantomdata/helpers.py:192-224 — for a voxel volume
  * vol[nx,ny,nz] (C order) on the regular grid axis_k = origin_k + i*spacing_k, trilinear interpolation with

@@ -74,6 +74,8 @@ _SIGS = {
     "afx_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "afx_fine_depths": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                   C.c_void_p, C.c_void_p]),
+    "afx_fine_depths_from_tau": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                           C.c_void_p, C.c_void_p]),
     "afx_grid_points": (C.c_int, [C.POINTER(GridDesc), C.c_void_p, C.c_int64, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
     "afx_grid_update": (C.c_int, [C.POINTER(GridDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_float, C.c_void_p]),
     "afx_grid_binarize": (C.c_int, [C.POINTER(GridDesc), C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

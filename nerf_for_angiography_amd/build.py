@@ -30,8 +30,8 @@ def _units():
     """(object name, source, extra defines)"""
     out = [("api", "afx_api.hip", [])]
     for f in (64, 128, 256):
-        for bwd in (0, 1):
-            out.append((f"chain16_w{f}_{'bwd' if bwd else 'fwd'}", "afx_inst_chain16.hip", [f"-DAFX_INST_F={f}", f"-DAFX_INST_BWD={bwd}"]))
+        for bwd in (0, 1, 2):
+            out.append((f"chain16_w{f}_{('fwd', 'bwd', 'phases')[bwd]}", "afx_inst_chain16.hip", [f"-DAFX_INST_F={f}", f"-DAFX_INST_BWD={bwd}"]))
     return out
 
 

@@ -26,6 +26,12 @@
 AFX_CHAIN16_FWD(AFX_CHAIN16_HERE, 64) AFX_CHAIN16_BWD(AFX_CHAIN16_HERE, 64)
 AFX_CHAIN16_FWD(AFX_CHAIN16_HERE, 128) AFX_CHAIN16_BWD(AFX_CHAIN16_HERE, 128)
 AFX_CHAIN16_FWD(AFX_CHAIN16_HERE, 256) AFX_CHAIN16_BWD(AFX_CHAIN16_HERE, 256)
+#ifdef AFX_SINGLE_TU
+#define AFX_CHAIN16_PH_HERE AFX_CHAIN16_PH_DEF
+#else
+#define AFX_CHAIN16_PH_HERE AFX_CHAIN16_PH_DECL
+#endif
+AFX_CHAIN16_PHASES(AFX_CHAIN16_PH_HERE, 64) AFX_CHAIN16_PHASES(AFX_CHAIN16_PH_HERE, 128) AFX_CHAIN16_PHASES(AFX_CHAIN16_PH_HERE, 256)
 
 using namespace afx;
 
@@ -57,6 +63,7 @@ struct afx_ctx {
   hipEvent_t ev_chain[2] = {nullptr, nullptr}, ev_wgrad[2] = {nullptr, nullptr};
   int overlap, persistent_chain;
   int small_in_kernel;   // first-/output-layer gradient sums inside the backward chain kernel (AFX_SMALL_IN_KERNEL=0: off)
+  int force_split;       // AFX_FORCE_SPLIT=1 (measurement): the split-phase training step also where the fused kernel applies
   int device;            // the HIP device this context was created on; every entry point checks it is current
   const float* coef_params = nullptr;   // afx_set_encoding_grad: fp32 flat parameters (W_0 is read from them) ...
   float* d_coef = nullptr;              // ... and where d loss / d fourier coefficients accumulates (null: coefficients are constants)
@@ -158,6 +165,8 @@ extern "C" int afx_create(const afx_model_desc* d, afx_ctx** out) {
   if (const char* e = getenv("AFX_OVERLAP")) c->overlap = atoi(e);
   if (const char* e = getenv("AFX_PERSISTENT")) c->persistent_chain = atoi(e);
   if (const char* e = getenv("AFX_SMALL_IN_KERNEL")) c->small_in_kernel = atoi(e) != 0;
+  c->force_split = 0;
+  if (const char* e = getenv("AFX_FORCE_SPLIT")) c->force_split = atoi(e) != 0;
   *out = c;
   return AFX_OK;
 }
@@ -246,10 +255,16 @@ struct BwdLayout {
 };
 static const int kSplits = 64;
 static const int kSmallBlocks = 1024;  // blocks (and partial records) of k_small_grads_bf16 / k_small_from_groups: 4 per CU, their record loop is latency-bound
-static BwdLayout bwd_layout(const afx_ctx* c, int prec, int64_t n_rays) {
+// per-tile bytes of the 8-bit-stash mode: 1-byte H_l / dZ'_l planes, the input stash, per-sample words (group exponents / g'), and the
+// tile's ReLU-mask image (split phases): (N+1) layers x NT tiles x 512 lanes x 2 B
+static size_t per_tile_s8(const afx_ctx* c) {
+  return (size_t)256 * (2 * ((size_t)c->d.n_hidden + 1) * c->d.width + 4 * 16 * nk0_of(c) + 4 + 4) + ((size_t)c->d.n_hidden + 1) * c->nt * 1024;
+}
+static BwdLayout bwd_layout(const afx_ctx* c, int prec, int64_t n_rays, int64_t groups_per_ray = 0) {
   const size_t F = c->d.width, N = c->d.n_hidden;
   BwdLayout B;
   size_t fixed = rup64((size_t)n_rays * 4, 256);   // dod (rays mode only)
+  fixed += rup64((size_t)n_rays * (size_t)groups_per_ray * 4, 256);      // optical-depth partials of the 32-sample groups (split training step)
   fixed += rup64((N + 2) * (size_t)kSplits * F * F * 4, 256);     // partial (slot N+1: the fourier-coefficient contraction)
   fixed += rup64((N + 2) * (size_t)kSplits * (F + 4) * 4, 256);   // partial2
   if (prec != AFX_PREC_F32) fixed += rup64((size_t)kSmallBlocks * (F * 16 * nk0_of(c) + 2 * F + 4) * 4, 256);   // partial_s
@@ -270,19 +285,18 @@ extern "C" int64_t afx_query(const afx_ctx* c, int what, int64_t a0, int64_t a1,
     case AFX_Q_PREPARED_BYTES: return (int64_t)prep_layout(c, (int)a0).total;
     case AFX_Q_FWD_WORKSPACE: return (int64_t)rup64((size_t)a0 * (size_t)(s_pad_of((int)a1) / GROUP) * 4, 256);
     case AFX_Q_BWD_WORKSPACE_MIN: {
-      BwdLayout B = bwd_layout(c, (int)a2, a0);
+      BwdLayout B = bwd_layout(c, (int)a2, a0, 128);
       return (int64_t)(B.fixed_bytes + 32 * B.per_tile_bytes + 1024);
     }
     case AFX_Q_BWD_WORKSPACE_FULL: {
-      BwdLayout B = bwd_layout(c, (int)a2, a0);
+      BwdLayout B = bwd_layout(c, (int)a2, a0, a0 > 0 ? s_pad_of((int)a1) / GROUP : 0);
       const int64_t samples = a0 > 0 ? a0 * s_pad_of((int)a1) : a1;
       int64_t tiles = (samples + bwd_tile((int)a2) - 1) / bwd_tile((int)a2);
       if (is_bf16((int)a2)) {      // a chunk never exceeds the 4 GiB layer plane the 32-bit stash offsets reach (run_backward): more is never used
         const uint64_t plane_rows = ((uint64_t)1 << 32) / ((uint64_t)c->d.width * 2);
         size_t need = (size_t)std::min<int64_t>(tiles, (int64_t)(plane_rows / bwd_tile((int)a2))) * B.per_tile_bytes;
         if ((int)a2 == AFX_PREC_F16S8 && c->small_in_kernel) {      // rays mode stashes 1-byte elements: twice the rows per plane, ~half the bytes per row
-          const size_t per8 = (size_t)256 * (2 * ((size_t)c->d.n_hidden + 1) * c->d.width + 4 * 16 * nk0_of(c) + 4);
-          need = std::max(need, (size_t)std::min<int64_t>(tiles, (int64_t)(2 * plane_rows / 256)) * per8);
+          need = std::max(need, (size_t)std::min<int64_t>(tiles, (int64_t)(2 * plane_rows / 256)) * per_tile_s8(c));
         }
         return (int64_t)(B.fixed_bytes + need + 1024);
       }
@@ -349,9 +363,11 @@ static int launch_chain_k(afx_ctx* c, K kern, int which, const ChainArgs& a, siz
 }
 
 template <int F>
-static int launch_chain_f(afx_ctx* c, int prec, bool bwd, const ChainArgs& a, size_t lds, int grid, hipStream_t st) {
+static int launch_chain_f(afx_ctx* c, int prec, bool bwd, const ChainArgs& a, size_t lds, int grid, hipStream_t st, int phase) {
   const int which = bwd ? AFX_K_CHAIN_BWD : AFX_K_CHAIN_FWD;
   const bool enc = c->d.enc != AFX_ENC_NONE;
+  if (phase == 1) return launch_chain_k(c, k_chain_bf16<F, false, false, true, 8, true, true, true, 1>, which, a, lds, grid, st, 512);
+  if (phase == 2) return launch_chain_k(c, k_chain_bf16<F, false, false, true, 8, true, true, true, 2>, which, a, lds, grid, st, 512);
   if (prec == AFX_PREC_F32)
     return bwd ? launch_chain_k(c, k_chain_f32<F, true>, which, a, lds, grid, st) : launch_chain_k(c, k_chain_f32<F, false>, which, a, lds, grid, st);
   if (prec == AFX_PREC_BF16X3 && !bwd)
@@ -376,7 +392,7 @@ static int launch_chain_f(afx_ctx* c, int prec, bool bwd, const ChainArgs& a, si
              : launch_chain_k(c, k_chain_bf16<F, false, false, false, 8>, which, a, lds, grid, st, 512);
 }
 
-static int launch_chain(afx_ctx* c, int prec, bool bwd, const ChainArgs& a, hipStream_t st) {
+static int launch_chain(afx_ctx* c, int prec, bool bwd, const ChainArgs& a, hipStream_t st, int phase = 0) {
   const int F = c->d.width, N = c->d.n_hidden;
   size_t lds = (size_t)a.small_bytes_pad + (size_t)(is_bf16(prec) ? chain_ring(bwd) : 2) * a.slot_bytes;
   const int ncg = (is_bf16(prec) && (bwd || prec == AFX_PREC_BF16 || is_f16(prec))) ? 2 : 1;
@@ -386,9 +402,9 @@ static int launch_chain(afx_ctx* c, int prec, bool bwd, const ChainArgs& a, hipS
   if (tiles <= 0) return AFX_OK;
   if (int rc = check_dev(c, "afx chain launch")) return rc;
   const int grid = (tiles < c->n_cu || !a.persistent) ? tiles : c->n_cu;    // persistent: one workgroup per CU loops over tiles
-  if (F == 64) return launch_chain_f<64>(c, prec, bwd, a, lds, grid, st);
-  if (F == 128) return launch_chain_f<128>(c, prec, bwd, a, lds, grid, st);
-  return launch_chain_f<256>(c, prec, bwd, a, lds, grid, st);
+  if (F == 64) return launch_chain_f<64>(c, prec, bwd, a, lds, grid, st, phase);
+  if (F == 128) return launch_chain_f<128>(c, prec, bwd, a, lds, grid, st, phase);
+  return launch_chain_f<256>(c, prec, bwd, a, lds, grid, st, phase);
 }
 
 static void fill_model(const afx_ctx* c, int prec, bool bwd, const void* prepared, ChainArgs& a) {
@@ -546,7 +562,10 @@ static int launch_wgrad8_t(afx_ctx* c, const WgradArgs& w, const ReduceArgs& rd,
 // Shared by afx_render_backward / afx_mlp_backward: chain (recompute + input-gradient chain +
 // stash) then the weight-gradient contraction, chunk by chunk.  `a` is fully filled except the
 // backward pointers; `head` bytes at the start of the workspace are already in use (dod).
-static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws, size_t ws_bytes, float* grad_flat, hipStream_t st) {
+// `split` (fused MSE step whose rays straddle tiles): the chain runs as PHASE 1, per-ray finish (pixel, dL/d(optical depth)), PHASE 2 -
+// a.dod / a.od_part / a.target / a.pixel / a.inv_n are set by the caller; chunks hold whole rays.
+static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws, size_t ws_bytes, float* grad_flat, hipStream_t st,
+                        bool split = false, int64_t n_rays = 0) {
   const int F = c->d.width, N = c->d.n_hidden;
   BwdLayout B = bwd_layout(c, prec, 0);
   const size_t fixed = head + B.fixed_bytes;
@@ -561,7 +580,11 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
   const size_t esz = s8 ? 1 : (b16 ? 2 : 4);            // stash element size
   const int k0ld = b16 ? 16 * nk0_of(c) : c->k0pad;     // row length of the encoded-input stash
   if (is_bf16(prec) && prec == AFX_PREC_F16S8 && a.mode == 1 && c->small_in_kernel)
-    B.per_tile_bytes = (size_t)256 * (2 * ((size_t)c->d.n_hidden + 1) * c->d.width + 4 * 16 * nk0_of(c) + 4);     // 1 byte per stash element
+    B.per_tile_bytes = per_tile_s8(c);     // 1 byte per stash element
+  if (split && !s8) return fail(AFX_E_INVALID, "split training step: needs the 8-bit-stash kernel (AFX_PREC_F16S8, no input encoding)");
+  // a chunk of the split step holds whole rays: a multiple of lcm(s_pad, tile) / tile tiles
+  int64_t ray_tiles = 1;
+  if (split) { int64_t x = a.s_pad, y = TILE; while (y) { const int64_t t_ = x % y; x = y; y = t_; } ray_tiles = a.s_pad / x; }
   if (ws_bytes < fixed + B.per_tile_bytes + 1024) return fail(AFX_E_WORKSPACE, "backward workspace %zu too small (min %zu)", ws_bytes, fixed + 32 * B.per_tile_bytes);
   const int64_t tiles = (a.n_total + TILE - 1) / TILE;
   int64_t chunk = (int64_t)((ws_bytes - fixed - 1024) / B.per_tile_bytes);      // 1 KiB slack for buffer alignment
@@ -577,11 +600,15 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
     const int64_t n_chunks = (tiles + chunk - 1) / chunk;
     chunk = (tiles + n_chunks - 1) / n_chunks;
   }
+  if (split && chunk < tiles) {
+    if (chunk < ray_tiles) return fail(AFX_E_WORKSPACE, "backward workspace too small for one group of whole rays (%lld tiles)", (long long)ray_tiles);
+    chunk = chunk / ray_tiles * ray_tiles;
+  }
   // Overlap mode: two half-size stash buffers; the weight-gradient kernels of chunk i run on a side stream while
   // the chain kernel of chunk i+1 runs on the caller's stream (one is MFMA/HBM-write heavy, the other HBM-read
   // bound).  Fork/join with events only; the side stream always rejoins the caller's stream before returning.
   int nbuf = 1;
-  if (c->overlap && chunk < tiles && chunk >= 8) {
+  if (c->overlap && chunk < tiles && chunk >= 8 && !split) {
     if (!c->side) {
       HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
       for (auto& e : c->ev_chain) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -598,12 +625,18 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
   uint32_t* gmax_words = (uint32_t*)(ws + off); off += 256;
   const bool h16 = is_f16(prec);
   const size_t rows = (size_t)chunk * TILE;
-  float *stash_h[2], *stash_dz[2], *stash_e[2], *graw[2];
+  float *stash_h[2], *stash_dz[2], *stash_e[2], *graw[2], *gpart[2];
+  char* masks[2];
   for (int bI = 0; bI < nbuf; ++bI) {
     stash_h[bI] = (float*)(ws + off); off += (size_t)(N + 1) * rows * F * esz;
     stash_dz[bI] = (float*)(ws + off); off += (size_t)(N + 1) * rows * F * esz;
     stash_e[bI] = (float*)(ws + off); off += rows * k0ld * 4;
     graw[bI] = (float*)(ws + off); off += rup64(rows * 4, 256);
+    gpart[bI] = nullptr; masks[bI] = nullptr;
+    if (s8) {
+      gpart[bI] = (float*)(ws + off); off += rows * 4;
+      masks[bI] = ws + off; off += (size_t)chunk * (N + 1) * c->nt * 1024;
+    }
   }
   a.stash_rows = (int64_t)rows;
   a.debug = 0;
@@ -625,7 +658,22 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
     if (nbuf == 2 && ci >= 2) HIPCHK(hipStreamWaitEvent(st, c->ev_wgrad[bI], 0));     // buffer bI has been consumed
     a.gmax = h16 ? gmax_words + 16 * bI : nullptr;
     if (h16) HIPCHK(hipMemsetAsync(a.gmax, 0, 4, st));
-    int rc = launch_chain(c, prec, true, a, st);
+    a.gpart = gpart[bI]; a.masks = masks[bI];
+    int rc;
+    if (split) {
+      // forward half of the chunk, then the per-ray reduction over the chunk's (whole) rays, then the backward half
+      ChainArgs p = a;
+      p.fused = 0;
+      rc = launch_chain(c, prec, true, p, st, 1);
+      if (rc) return rc;
+      const int64_t ray0 = t0 * TILE / a.s_pad;
+      int64_t ray1 = t1 * TILE / a.s_pad;
+      if (ray1 > n_rays || t1 == tiles) ray1 = n_rays;
+      const int gpr = a.s_pad / GROUP;
+      hipLaunchKernelGGL(k_finish_mse, dim3((unsigned)((ray1 - ray0 + 255) / 256)), dim3(256), 0, st, (const float*)a.od_part + ray0 * gpr, gpr,
+                         ray1 - ray0, a.target + ray0, a.inv_n, a.pixel + ray0, (float*)a.dod + ray0);
+      rc = launch_chain(c, prec, true, p, st, 2);
+    } else rc = launch_chain(c, prec, true, a, st);
     if (rc) return rc;
     hipStream_t ws_st = st;
     if (nbuf == 2) {
@@ -649,6 +697,7 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
     w.rows_per_split = (int)rps;
     w.partial = partial; w.partial2 = partial2; w.partial_s = partial_s; w.debug = a.debug; w.small_groups = sg ? 1 : 0;
     w.gmax = a.gmax; w.stash_esz = (int)esz; w.gexp = a.gexp; w.enc16 = enc16 ? 1 : 0; w.coef_cols = a.coef_cols;
+    w.dod = split ? a.dod : nullptr; w.gpr = a.s_pad / GROUP; w.group0 = t0 * (TILE / GROUP);
     ReduceArgs rd;
     rd.partial = partial; rd.partial2 = partial2; rd.n_hidden = N; rd.k0 = c->k0; rd.k0pad = k0ld; rd.n_splits = splits;
     rd.grad = grad_flat; rd.hidden_only = b16 ? 1 : 0; rd.partial_s = partial_s;
@@ -698,13 +747,29 @@ extern "C" int afx_train_step_mse(afx_ctx* c, int prec, const void* prepared, co
   if (rc) return rc;
   if (!is_bf16(prec)) return fail(AFX_E_INVALID, "afx_train_step_mse: needs a bf16 precision (use afx_render_forward/backward for f32)");
   if (!prepared || !target || !grad_flat || !r->workspace) return fail(AFX_E_INVALID, "afx_train_step_mse: null argument");
-  if (256 % s_pad_of(r->n_samples) != 0) return fail(AFX_E_INVALID, "afx_train_step_mse: padded samples per ray (%d) must divide 256", (int)s_pad_of(r->n_samples));
+  const int64_t s_pad = s_pad_of(r->n_samples);
+  // rays inside one workgroup tile: ONE kernel per chunk.  Otherwise (the reference's own 300 samples per ray, the 128 + 64 of the
+  // hierarchical pass) the same work as two launches per chunk - forward half, per-ray reduction, backward half - for the
+  // 8-bit-stash kernel; other precisions refuse (the Python layer renders, then calls afx_render_backward, which recomputes the forward)
+  const bool split = 256 % s_pad != 0;
+  const bool can_split = prec == AFX_PREC_F16S8 && c->d.enc == AFX_ENC_NONE && c->small_in_kernel;
+  if (split && !can_split)
+    return fail(AFX_E_INVALID, "afx_train_step_mse: padded samples per ray (%d) must divide 256 at this precision / encoding", (int)s_pad);
   ChainArgs a = {};
   fill_model(c, prec, true, prepared, a);
   fill_render(r, a);
   a.sigma = nullptr; a.tau = nullptr;
   a.fused = 1; a.target = target; a.pixel = r->pixel; a.inv_n = inv_n;
-  return run_backward(c, prec, a, 0, (char*)r->workspace, r->workspace_bytes, grad_flat, (hipStream_t)stream);
+  const bool do_split = split || (can_split && c->force_split);
+  size_t head = 0;
+  if (do_split) {
+    const size_t dod_bytes = rup64((size_t)r->n_rays * 4, 256), od_bytes = rup64((size_t)r->n_rays * (size_t)(s_pad / GROUP) * 4, 256);
+    if (r->workspace_bytes < dod_bytes + od_bytes) return fail(AFX_E_WORKSPACE, "afx_train_step_mse: workspace too small");
+    a.dod = (const float*)r->workspace;
+    a.od_part = (float*)((char*)r->workspace + dod_bytes);
+    head = dod_bytes + od_bytes;
+  }
+  return run_backward(c, prec, a, head, (char*)r->workspace, r->workspace_bytes, grad_flat, (hipStream_t)stream, do_split, r->n_rays);
 }
 
 extern "C" int afx_mlp_backward(afx_ctx* c, int prec, const void* prepared, const float* pts, int64_t n_pts,
@@ -788,16 +853,26 @@ extern "C" int afx_composite_packed_backward(const float* pred, const int32_t* r
   return AFX_OK;
 }
 
-extern "C" int afx_fine_depths(const float* z_coarse, int z_per_ray, const float* w_coarse, const float* u, int64_t n_rays,
-                               int32_t n_coarse, int32_t n_fine, float* z_out, void* stream) {
-  if (!z_coarse || !w_coarse || !u || !z_out) return fail(AFX_E_INVALID, "afx_fine_depths: null argument");
-  if (n_coarse < 3 || n_coarse > AFX_MAX_COARSE) return fail(AFX_E_INVALID, "afx_fine_depths: n_coarse must be in 3..%d", AFX_MAX_COARSE);
-  if (n_fine < 1 || n_fine > AFX_MAX_FINE) return fail(AFX_E_INVALID, "afx_fine_depths: n_fine must be in 1..%d", AFX_MAX_FINE);
+static int fine_depths_impl(const char* who, const float* z_coarse, int z_per_ray, const float* w_coarse, const float* tau, const float* u,
+                            int64_t n_rays, int32_t n_coarse, int32_t n_fine, float* z_out, void* stream) {
+  if (!z_coarse || (!w_coarse && !tau) || !u || !z_out) return fail(AFX_E_INVALID, "%s: null argument", who);
+  if (n_coarse < 3 || n_coarse > AFX_MAX_COARSE) return fail(AFX_E_INVALID, "%s: n_coarse must be in 3..%d", who, AFX_MAX_COARSE);
+  if (n_fine < 1 || n_fine > AFX_MAX_FINE) return fail(AFX_E_INVALID, "%s: n_fine must be in 1..%d", who, AFX_MAX_FINE);
   if (n_rays <= 0) return AFX_OK;
   hipLaunchKernelGGL(k_fine_depths, dim3((unsigned)((n_rays + 63) / 64)), dim3(64), 0, (hipStream_t)stream, z_coarse, z_per_ray,
-                     w_coarse, u, n_rays, n_coarse, n_fine, z_out);
+                     w_coarse, tau, u, n_rays, n_coarse, n_fine, z_out);
   HIPCHK(hipGetLastError());
   return AFX_OK;
+}
+
+extern "C" int afx_fine_depths(const float* z_coarse, int z_per_ray, const float* w_coarse, const float* u, int64_t n_rays,
+                               int32_t n_coarse, int32_t n_fine, float* z_out, void* stream) {
+  return fine_depths_impl("afx_fine_depths", z_coarse, z_per_ray, w_coarse, nullptr, u, n_rays, n_coarse, n_fine, z_out, stream);
+}
+
+extern "C" int afx_fine_depths_from_tau(const float* z_coarse, int z_per_ray, const float* tau_coarse, const float* u, int64_t n_rays,
+                                        int32_t n_coarse, int32_t n_fine, float* z_out, void* stream) {
+  return fine_depths_impl("afx_fine_depths_from_tau", z_coarse, z_per_ray, nullptr, tau_coarse, u, n_rays, n_coarse, n_fine, z_out, stream);
 }
 
 

@@ -22,3 +22,9 @@
   extern template __global__ void k_chain_bf16<F, X3, ENC, BWD, NW, SG, H16, S8>(const afx::ChainArgs);
 #define AFX_CHAIN16_DEF(F, X3, ENC, BWD, NW, SG, H16, S8) \
   template __global__ void k_chain_bf16<F, X3, ENC, BWD, NW, SG, H16, S8>(const afx::ChainArgs);
+// split phases of the 8-bit-stash training kernel (PHASE 1 = forward half, 2 = backward half)
+#define AFX_CHAIN16_PHASES(X, F) X(F, 1) X(F, 2)
+#define AFX_CHAIN16_PH_DECL(F, PH) \
+  extern template __global__ void k_chain_bf16<F, false, false, true, 8, true, true, true, PH>(const afx::ChainArgs);
+#define AFX_CHAIN16_PH_DEF(F, PH) \
+  template __global__ void k_chain_bf16<F, false, false, true, 8, true, true, true, PH>(const afx::ChainArgs);

@@ -82,6 +82,9 @@ struct ChainArgs {
   int32_t stash8;           // f16 mode: 8-bit (bf8) stash of H_l and dZ'_l
   int32_t* gexp;            // 8-bit stash: power-of-two exponent of each 32-sample group's largest |dL/draw| [rows/32]
   int32_t coef_cols;        // 3*n_freq when the fourier coefficients train (the chain kernel then also stashes d(enc)/d(coef)/(2 pi)), else 0
+  // split phases of the 8-bit-stash training kernel (rays that straddle workgroup tiles)
+  char* masks;              // [tiles of the chunk][(N+1) x NT x 512 x u16]: the ReLU-mask LDS image of each tile (PHASE 1 writes, PHASE 2 reads)
+  float* gpart;             // [rows] g' = dt sigma (1 - sigma) of each sample (PHASE 1 writes, PHASE 2 reads)
 };
 
 struct WgradArgs {
@@ -104,6 +107,10 @@ struct WgradArgs {
   int32_t enc16;            // 16-bit kernels with an encoding: stash_e is the 16-bit chunk-major input stash; k_wgrad_bf16 contracts layer 0 on
                             // the matrix pipe (blockIdx.y = n_hidden) and, with coef_cols > 0, d(enc)/d(coef) as well (blockIdx.y = n_hidden + 1)
   int32_t coef_cols;        // 3*n_freq when the fourier coefficients train, else 0
+  // split phases: the output-layer group sums were formed with g' (without the ray's dL/d(optical depth)); k_small_from_groups applies it
+  const float* dod;         // [n_rays] or null (fused kernel: the sums already carry it)
+  int32_t gpr;              // 32-sample groups per ray (s_pad / 32)
+  int64_t group0;           // global index of the chunk's first group
 };
 
 struct ReduceArgs {

@@ -217,8 +217,18 @@ template <int K> __device__ __forceinline__ void lds_wait_frag(u32x4& r) {
 // (dW_out += SW, db_0 += S0, dW_0 += S0 c^T + S1 d^T; k_small_from_groups).  The sums run over the LANE dimension
 // of the fragments; an MFMA against a 0/1 selection matrix transposes a fragment exactly (bf16 x 1.0, fp32
 // accumulate) into the C layout - lane = feature position, 16 registers = samples - where the sum is 16 VALU FMAs.
-template <int F, bool X3, bool ENC, bool BWD, int NW, bool SG = false, bool H16 = false, bool S8 = false>
+// PHASE (8-bit-stash training kernel, rays mode): 0 = the fused kernel (forward, compositing, backward in one pass: needs every ray inside
+// one workgroup tile).  1 / 2 = the same work as TWO launches for rays that straddle tiles (samples per ray not a divisor of the
+// tile: the reference's own 300, the 128 + 64 of the hierarchical pass): PHASE 1 is the forward half - it stashes H_l, leaves the
+// ReLU masks of its tile (the LDS image, as it is) and g' = dt sigma (1 - sigma) per sample in HBM, the optical-depth partials of the
+// 32-sample groups and the output-layer group sums weighted by g' (dL/d(optical depth) of the ray is not known yet; it is a
+// factor common to a group, applied by k_small_from_groups); after the per-ray reduction (k_finish_mse: pixel, dL/d(optical depth))
+// PHASE 2, the backward half, loads the masks back into LDS by LDS-DMA and runs the input-gradient chain with g = dod[ray] g'.
+// Nothing is computed twice (the two-launch path it replaces rendered the forward, then recomputed it inside the backward kernel).
+template <int F, bool X3, bool ENC, bool BWD, int NW, bool SG = false, bool H16 = false, bool S8 = false, int PHASE = 0>
 __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs a) {
+  static_assert(PHASE == 0 || (S8 && !ENC && PHASE <= 2), "split phases: the 8-bit-stash kernel without an input encoding");
+  constexpr bool P1 = PHASE == 1, P2 = PHASE == 2;
   static_assert(!S8 || (SG && H16), "8-bit stash: f16 backward kernel with in-kernel small gradients");
   static_assert(!SG || (BWD && !X3 && (!ENC || S8)), "in-kernel small gradients: plain backward kernel; with an encoding only the 8-bit-stash kernel");
   static_assert(!(H16 && (X3 || NW != 8)), "f16 hidden layers: 8-wave kernels only");
@@ -259,7 +269,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
   // The prepared buffer holds [first-layer slabs | forward hidden slabs (hi) | transposed slabs] as ONE contiguous
   // stream in the order a tile consumes it (the lo parts of the split mode are a second stream): the source of the
   // next request is a running scalar pointer, and every request is a straight-line run of 1 KiB LDS-DMA pieces.
-  const char* wnext = a.stream_fwd;
+  const char* wnext = P2 ? a.stream_bwd : a.stream_fwd;      // (the transposed slabs are the tail of the one contiguous stream)
   const char* lnext = a.stream_lo;
   const uint32_t voff = (uint32_t)wave * 1024u + (uint32_t)lane * 16u;
   auto dma_run = [&](const char* src, char* dst, auto bytes_c) {
@@ -271,13 +281,13 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
   };
   // Request cursor: runs PD steps ahead of the compute, across tile boundaries, until every step of this
   // workgroup's tiles has been requested.
-  const int steps_per_tile = SPL * (N + 1) + (BWD ? SPL * N : 0);
+  const int steps_per_tile = P2 ? SPL * N : SPL * (N + 1) + ((BWD && !P1) ? SPL * N : 0);
   int to_issue = ((a.tile1 - a.tile0 - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x) * steps_per_tile;
   int cpos = 0;                           // position of the next requested step inside its tile
   uint32_t wslot = 0, rslot = 0;          // ring slot of the next request / of the next step to compute
   auto request = [&]() {
     char* dst = slot0 + wslot * SLOT;
-    if (cpos < SPL) {
+    if (!P2 && cpos < SPL) {
       dma_run(wnext, dst, std::integral_constant<uint32_t, STEP0>{});
       wnext += STEP0;
     } else {
@@ -288,7 +298,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
         lnext += STEPH;
       }
     }
-    if (++cpos == steps_per_tile) { cpos = 0; wnext = a.stream_fwd; lnext = a.stream_lo; }
+    if (++cpos == steps_per_tile) { cpos = 0; wnext = P2 ? a.stream_bwd : a.stream_fwd; lnext = a.stream_lo; }
     wslot = wslot + 1 == RING ? 0 : wslot + 1;
     --to_issue;
   };
@@ -317,7 +327,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
   // `counted` = false: the previous step issued no stash stores (SG: the last forward layer's H_N is not stashed)
   // GAPS (8-bit stash kernel): stash stores move between tiles, so the wave counts them; a step that issued fewer than SPS
   // behind its request is followed by a full wait (wave-uniform scalar counter).
-  constexpr bool GAPS = S8 && AFX_GAPS;
+  constexpr bool GAPS = S8 && AFX_GAPS && PHASE == 0;
   constexpr int IPG = 16 / (2 * NT);     // work items per MFMA gap (GAPS)
   int nstores = 0;
   // GAPS: a hidden step's request is issued piece by piece in the first MFMA gaps of the step's first tile (defer = true):
@@ -377,7 +387,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
       sp[cg] = make_sample(a, n[cg]);
       // first-layer B fragments: element j of k-step q is encoded input k = 16q + 8*(lane>>5) + j
 #pragma unroll
-      for (int q = 0; q < NK0; ++q) {
+      for (int q = 0; q < (P2 ? 0 : NK0); ++q) {
         float e[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -560,11 +570,13 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
       __builtin_amdgcn_sched_barrier(0);
     };
 
+    if constexpr (!P2) {      // ======== forward half
     // ---------------- layer 0 (always split: hi*hi + hi*lo + lo*hi)
     {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        if (t % TPS == 0) stepbase = step_begin();
+        // (PHASE 1: the step before a tile's first one is the previous tile's last layer, which stores nothing: full wait)
+        if (t % TPS == 0) stepbase = step_begin(!(P1 && t == 0));
         const u32x4* sl = (const u32x4*)(stepbase + (t % TPS) * SLAB0);     // [(q*2 + part)*64 + lane]
         f32x16 acc[NCG];
 #pragma unroll
@@ -697,6 +709,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
       }
     }
 
+    }      // ======== end of the forward half
+
     // ---------------- output layer + Beer-Lambert / outputs
     float g[NCG];
 #pragma unroll
@@ -705,7 +719,9 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
       d += __shfl_xor(d, 32);
       const float raw = d + sm[(N + 2) * F];
       g[cg] = 0.f;
-      if (a.mode == 0) {
+      if constexpr (P2) {      // backward half: dL/draw = dL/d(optical depth of the ray) * g' (PHASE 1 left g' = dt sigma (1 - sigma))
+        g[cg] = sp[cg].live ? a.dod[sp[cg].ray] * a.gpart[m[cg]] : 0.f;
+      } else if (a.mode == 0) {
         if (!BWD) { if (hh == 0 && sp[cg].live) a.out[n[cg]] = a.apply_sigmoid ? sigmoidf_(raw) : raw; }
         else g[cg] = sp[cg].live ? a.dod[n[cg]] : 0.f;
       } else {
@@ -715,13 +731,17 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
           if (a.sigma) a.sigma[(int64_t)sp[cg].ray * a.n_samples + sp[cg].s] = sig;
           if (a.tau) a.tau[(int64_t)sp[cg].ray * a.n_samples + sp[cg].s] = tau;
         }
-        if (!BWD) {
+        if (!BWD || P1) {
           float od = tau;
 #pragma unroll
           for (int sh = 16; sh >= 1; sh >>= 1) od += __shfl_xor(od, sh);
           if (lane == 0 && n[cg] < a.n_total) {
             const int gpr = a.s_pad / GROUP;
             a.od_part[(int64_t)sp[cg].ray * gpr + (n[cg] - sp[cg].ray * a.s_pad) / GROUP] = od;
+          }
+          if constexpr (P1) {      // g' of the sample: everything of dL/draw but the ray's dL/d(optical depth)
+            g[cg] = sp[cg].live ? sp[cg].dt * (sig * (1.f - sig)) : 0.f;
+            if (hh == 0) a.gpart[m[cg]] = g[cg];
           }
         } else if (a.fused) {
           // fused training step: every ray lies inside this workgroup tile (host guarantees s_pad | TS).
@@ -735,7 +755,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
         } else if (sp[cg].live) g[cg] = a.dod[sp[cg].ray] * sp[cg].dt * (sig * (1.f - sig));
       }
     }
-    if (BWD && a.mode != 0 && a.fused) {
+    if (BWD && PHASE == 0 && a.mode != 0 && a.fused) {
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       const float* odb = (const float*)(slot0 + RING * (size_t)SLOT + (size_t)(N + 1) * MW * NCG * NTH * 4);
       const int gpr = a.s_pad / GROUP;
@@ -770,6 +790,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
         for (int q = 0; q < 4; ++q)      // 1.0 in the operand type: bf16 0x3f80, f16 0x3c00
           sel[s2][q] = (e == 2 * q) ? (H16 ? 0x00003c00u : 0x00003f80u) : ((e == 2 * q + 1) ? (H16 ? 0x3c000000u : 0x3f800000u) : 0u);
       }
+    }
+    if constexpr (SG && !P2) {      // (PHASE 1: g = g', the common factor dod of the group's ray is applied by k_small_from_groups)
 #pragma unroll
       for (int cg = 0; cg < NCG; ++cg) {
         float* rec = a.small_part + (size_t)(m[cg] >> 5) * (3 * F + 8);
@@ -790,7 +812,25 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
         if (lane == 0) rec[3 * F + 6] = sg;
       }
     }
-    if (BWD) {
+    constexpr uint32_t MASKB = 2u * NT * NCG * NTH;      // mask bytes per layer (the LDS image, [((l*NT + t)*NCG + cg)*NTH + tid] u16)
+    if constexpr (P1) {
+      // the tile's ReLU masks, as they lie in LDS, go to HBM for the backward half: a cooperative 16-byte copy
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave's mask words are written
+      char* mg = a.masks + (size_t)(tile - a.tile0) * ((size_t)(N + 1) * MASKB);
+      for (uint32_t off = (uint32_t)tid * 16u; off < (uint32_t)(N + 1) * MASKB; off += NTH * 16u)
+        __builtin_nontemporal_store(*(const u32x4*)((const char*)mk16 + off), (u32x4*)(mg + off));
+      // (the next tile overwrites the LDS image only behind its first step barrier, which every wave reaches after issuing these stores,
+      // i.e. after its LDS reads have returned)
+    }
+    if constexpr (P2) {
+      // masks of this tile: HBM -> LDS by LDS-DMA (1 KiB per wave instruction), behind a barrier that retires every reader of the previous tile's
+      asm volatile("s_barrier" ::: "memory");
+      const char* mg = a.masks + (size_t)(tile - a.tile0) * ((size_t)(N + 1) * MASKB);
+      for (uint32_t off = (uint32_t)wave * 1024u; off < (uint32_t)(N + 1) * MASKB; off += NW * 1024u)
+        __builtin_amdgcn_global_load_lds(GPTR(mg + off + lane * 16), LPTR((char*)mk16 + off), 16, 0, 0);
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    if constexpr (BWD && !P1) {
       // ---------------- input-gradient chain, 16-bit operands, fp32 accumulate.  bf16: dZ_l.  H16: J_l = dZ_l / g.
       u32x4 dz[NCG][NT][2];
       unsigned ghat2[NCG];
@@ -1412,10 +1452,12 @@ __global__ void __launch_bounds__(F) k_small_from_groups(const WgradArgs a) {
 #pragma unroll 4
   for (int64_t g = g0; g < g1; ++g) {
     const float* rec = base + g * RS;
-    const float sw = rec[p];
+    // (split phases: SW and sum g were formed with g' = g / dod[ray]; a group never straddles rays)
+    const float ds = a.dod ? a.dod[(a.group0 + g) / a.gpr] : 1.f;
+    const float sw = rec[p] * ds;
     if (a.enc16) {          // encoded inputs: only the output layer's sums are in the records (first layer: k_wgrad_s8)
       aw += sw;
-      sg += rec[3 * F + 6];
+      sg += rec[3 * F + 6] * ds;
       continue;
     }
     const float s0 = rec[F + p], s1 = rec[2 * F + p];
@@ -1426,7 +1468,7 @@ __global__ void __launch_bounds__(F) k_small_from_groups(const WgradArgs a) {
     ax += fmaf(c4[0], s0, c4[3] * s1);
     ay += fmaf(c4[1], s0, d4[0] * s1);
     az += fmaf(c4[2], s0, d4[1] * s1);
-    sg += d4[2];
+    sg += d4[2] * ds;
   }
   const size_t SS = (size_t)F * a.k0pad + 2 * F + 4;
   float* P = a.partial_s + (size_t)blockIdx.x * SS;

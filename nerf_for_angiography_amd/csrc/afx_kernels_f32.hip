@@ -721,6 +721,18 @@ __global__ void k_finish_fwd(const float* od_part, int groups, int64_t n_rays, f
   pixel[r] = expf(-od);
 }
 
+// split training step (rays that straddle tiles): pixel = exp(-sum of the ray's group partials) and, for
+// L = inv_n sum_r (pixel_r - target_r)^2, dL/d(optical depth) = -pixel * 2 (pixel - target) inv_n  (nerf/run_nerf_acc.py:296-298,306)
+__global__ void k_finish_mse(const float* od_part, int groups, int64_t n_rays, const float* target, float inv_n, float* pixel, float* dod) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rays) return;
+  float od = 0.f;
+  for (int g = 0; g < groups; ++g) od += od_part[r * groups + g];
+  const float T = expf(-od);
+  pixel[r] = T;
+  dod[r] = -T * (2.f * (T - target[r]) * inv_n);
+}
+
 // dL/d(optical depth) = -pixel * dL/dpixel
 __global__ void k_finish_bwd(const float* pixel, const float* dpix, int64_t n_rays, float* dod) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -875,22 +887,33 @@ __global__ void k_project_volume(const ChainArgs a, const VolArgs v) {
 // sample_pdf + merge of fine_sampling (nerf/nerf_helpers.py:178-222); one thread per ray.
 #define AFX_MAX_COARSE 512
 #define AFX_MAX_FINE 512
-__global__ void k_fine_depths(const float* zc, int z_per_ray, const float* wc, const float* u, int64_t n_rays,
+// tau != nullptr: the coarse pass's per-sample optical depths [R,S] instead of its weights: the weights of render_volume_density
+// (nerf_helpers.py:107-108), w_i = (1 - alpha_i + 1e-10) prod_{j<i} alpha_j with alpha = exp(-tau), are formed here, per ray, in order.
+__global__ void k_fine_depths(const float* zc, int z_per_ray, const float* wc, const float* tau, const float* u, int64_t n_rays,
                               int S, int NF, float* zout) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n_rays) return;
   const float* z = z_per_ray ? zc + r * S : zc;
-  const float* w = wc + r * S + 1;      // weights[..., 1:-1]  -> S-2 values
   const int nb = S - 1;                  // bins = mid-points, cdf has nb entries
   float cdf[AFX_MAX_COARSE];
   float smp[AFX_MAX_FINE];
+  if (tau) {                             // cdf[] holds weights[1 .. S-2] for a moment
+    float T = expf(-tau[r * S]);         // exclusive transmittance in front of sample 1
+    for (int i = 1; i < S - 1; ++i) {
+      const float al = expf(-tau[r * S + i]);
+      cdf[i] = __fmul_rn(__fadd_rn(__fsub_rn(1.f, al), 1e-10f), T);
+      T = __fmul_rn(T, al);
+    }
+  } else {
+    for (int i = 1; i < S - 1; ++i) cdf[i] = wc[r * S + i];      // weights[..., 1:-1]  -> S-2 values
+  }
   float wsum = 0.f;
-  for (int i = 0; i < S - 2; ++i) wsum = __fadd_rn(wsum, __fadd_rn(w[i], 1e-5f));
+  for (int i = 1; i < S - 1; ++i) wsum = __fadd_rn(wsum, __fadd_rn(cdf[i], 1e-5f));
   cdf[0] = 0.f;
   float run = 0.f;
-  for (int i = 0; i < S - 2; ++i) {
-    run = __fadd_rn(run, __fadd_rn(w[i], 1e-5f) / wsum);
-    cdf[i + 1] = run;
+  for (int i = 1; i < S - 1; ++i) {
+    run = __fadd_rn(run, __fadd_rn(cdf[i], 1e-5f) / wsum);
+    cdf[i] = run;
   }
   for (int k = 0; k < NF; ++k) {
     const float uu = u[r * NF + k];

@@ -5,6 +5,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -260,6 +261,14 @@ class Engine:
         del keep
 
 
+    def fused_step_available(self, n_samples: int, prec: str) -> bool:
+        """afx_train_step_mse takes this ray length at this precision: rays that fit a 256-sample workgroup tile always (one
+        kernel per chunk); any other length (300, 128 + 64, ...) as two half-kernels per chunk with the 8-bit-stash kernel, no
+        input encoding (include/afx.h)."""
+        s_pad = (int(n_samples) + 31) // 32 * 32
+        return 256 % s_pad == 0 or (prec == "f16s8" and self.enc == "none" and os.environ.get("AFX_SMALL_IN_KERNEL", "1") != "0"
+                                    and os.environ.get("AFX_NO_SPLIT", "0") == "0")      # (AFX_NO_SPLIT=1: A/B against the two-launch path)
+
     def train_step_mse(self, prepared, spec: RenderSpec, target, inv_n: float, grad_flat, prec: str):
         """Fused forward + MSE + backward (afx_train_step_mse); returns the rendered pixels."""
         dev = prepared.device
@@ -268,8 +277,7 @@ class Engine:
             raise ValueError("target: one value per ray expected")
         pixel = torch.empty(spec.n_rays, dtype=torch.float32, device=dev)
         a, keep = self._render_args(spec, dev, pixel)
-        full = int(self.lib.afx_query(self.h, _lib.Q_BWD_WORKSPACE_FULL, 0, spec.n_rays * ((spec.n_samples + 31) // 32 * 32),
-                                      _lib.PREC[prec]))
+        full = int(self.lib.afx_query(self.h, _lib.Q_BWD_WORKSPACE_FULL, spec.n_rays, spec.n_samples, _lib.PREC[prec]))
         ws = self._workspace(min(full, self.max_workspace_bytes), dev)
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
         self._check(self.lib.afx_train_step_mse(self.h, _lib.PREC[prec], _ptr(prepared), C.byref(a), _ptr(target),
@@ -371,6 +379,19 @@ def fine_depths(z_coarse, w_coarse, u):
     out = torch.empty(r, s + nf, device=dev)
     _lib.check(lib.afx_fine_depths(_ptr(z_coarse), int(z_coarse.dim() == 2), _ptr(w_coarse), _ptr(u), r, s, nf, _ptr(out),
                                    Engine._stream(dev)), "afx_fine_depths")
+    return out
+
+
+def fine_depths_from_tau(z_coarse, tau_coarse, u):
+    """afx_fine_depths_from_tau: merged coarse + fine depths from the coarse pass's per-sample optical depths [R,S]."""
+    lib = _lib.load()
+    dev = tau_coarse.device
+    z_coarse, tau_coarse, u = _f32(z_coarse, "z_coarse", dev), _f32(tau_coarse, "tau_coarse", dev), _f32(u, "u", dev)
+    r, s = tau_coarse.shape
+    nf = u.shape[1]
+    out = torch.empty(r, s + nf, device=dev)
+    _lib.check(lib.afx_fine_depths_from_tau(_ptr(z_coarse), int(z_coarse.dim() == 2), _ptr(tau_coarse), _ptr(u), r, s, nf, _ptr(out),
+                                            Engine._stream(dev)), "afx_fine_depths_from_tau")
     return out
 
 

@@ -150,13 +150,14 @@ def train_step_mse(model, spec: RenderSpec, target: torch.Tensor, n_global: Opti
     n = _global_rays(spec.n_rays, n_global, model.flat_params.device)
     flat_grad = torch.zeros(model.engine.param_count, dtype=torch.float32, device=model.flat_params.device)
     coef_grad = model._coef_grad_buffer()
-    s_pad = (spec.n_samples + 31) // 32 * 32
     with model.engine.encoding_grad(model.flat_params, coef_grad):
-        if 256 % s_pad == 0:
+        if model.engine.fused_step_available(spec.n_samples, model.precision):
+            # one kernel per ray chunk - or, for rays that straddle workgroup tiles (the reference's 300 samples/ray, the 128 + 64 of
+            # the hierarchical pass) at the default precision, its two halves with the per-ray reduction between them: no recompute
             pixel = model.engine.train_step_mse(model._prepared(), spec, target, 1.0 / n, flat_grad, model.precision)
         else:
-            # a ray would straddle workgroup tiles (e.g. the reference's 300 samples/ray): same arithmetic in two
-            # launches - forward, then the backward kernel with dL/dpixel = 2 (pixel - target) / n
+            # such rays at the other precisions / with an input encoding: forward launch, then the backward kernel (which recomputes
+            # the forward) with dL/dpixel = 2 (pixel - target) / n
             pixel, _, _ = model.engine.render_forward(model._prepared(), spec, model.precision)
             d_pixel = (pixel - _as_f32(target, pixel.device)) * (2.0 / n)
             model.engine.render_backward(model._prepared(), spec, pixel, d_pixel, flat_grad, model.precision)
@@ -171,6 +172,39 @@ def train_step_mse(model, spec: RenderSpec, target: torch.Tensor, n_global: Opti
             p.grad.add_(g)
     loss = torch.nn.functional.mse_loss(pixel, target) if n == spec.n_rays else ((pixel - target) ** 2).sum() / n
     return loss, pixel
+
+
+def hierarchical_train_step_mse(model, ray_origins, ray_directions, depth_values, depth_samples_per_ray_fine: int,
+                                target: torch.Tensor, u: Optional[torch.Tensor] = None, n_global: Optional[int] = None,
+                                fine_model=None):
+    """One hierarchical (coarse + fine) training pass on the fused kernels - the training step `fine_sampling`
+    (nerf/nerf_helpers.py:178-195) belongs to, for the one-channel absorption model and an MSE loss on the fine render:
+
+      coarse pass, no gradient (the reference detaches the samples, :186): ONE forward launch over the S coarse depths, which
+        leaves the per-sample optical depths tau[R,S];
+      afx_fine_depths_from_tau: weights = (1 - alpha + 1e-10) cumprod_exclusive(alpha) per ray, inverse-CDF sampling of
+        `depth_samples_per_ray_fine` depths from weights[..., 1:-1] over the mid-point bins (sample_pdf, :197-222), merge with
+        the coarse depths - nothing [R,S]-shaped is formed by torch operators in between;
+      fine pass over the S + N_f per-ray depths with `fine_model or model`: train_step_mse (dense convention) - forward,
+        compositing, MSE gradient and backward without recomputing the forward (128 + 64 = 192 samples straddle the 256-sample
+        workgroup tiles: the split-phase step of afx_train_step_mse at the f16s8 precision).
+
+    Gradients are accumulated into `.grad` of the fine network as train_step_mse does.  Returns (loss, fine pixels, merged depths)."""
+    _check_model(model)
+    from . import engine as _engine
+    n_rays = ray_origins.shape[0]
+    z = depth_values
+    with torch.no_grad():
+        spec_c = RenderSpec(n_rays=n_rays, n_samples=int(z.shape[-1]), origins=ray_origins, dirs=ray_directions, mode="dense", z=z)
+        _, _, tau = model.engine.render_forward(model._prepared(), spec_c, model.precision, want_tau=True)
+        if u is None:
+            u = torch.rand(n_rays, int(depth_samples_per_ray_fine), device=tau.device)
+        z_all = _engine.fine_depths_from_tau(z, tau, u)
+        del tau
+    net = model if fine_model is None else fine_model
+    spec_f = RenderSpec(n_rays=n_rays, n_samples=int(z_all.shape[-1]), origins=ray_origins, dirs=ray_directions, mode="dense", z=z_all)
+    loss, pixel = train_step_mse(net, spec_f, target, n_global)
+    return loss, pixel, z_all
 
 
 def projection_spec(poses, width, height, focal, depth_samples_per_ray, near_thresh, far_thresh, ray_ids=None,

@@ -313,3 +313,167 @@ def test_full_size_gpu_tests_at_the_bench_workspace_setting():
         del m
         torch.cuda.empty_cache()
     assert float((flat[24] - flat[128]).norm() / flat[128].norm()) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ split-phase fused train step
+def _ref_iteration_problem(n_rays, seed=11):
+    g = torch.Generator().manual_seed(seed)
+    o = torch.tensor([[0.0, 0.0, 1500.0]]).repeat(n_rays, 1) + torch.randn(n_rays, 3, generator=g)
+    d = torch.nn.functional.normalize(torch.randn(n_rays, 3, generator=g) * 0.03 + torch.tensor([0, 0, -1.0]), dim=-1)
+    return o, d, torch.rand(n_rays, generator=g)
+
+
+@pytest.mark.parametrize("layers,width,n_samples,n_rays", [(4, 128, 300, 5625), (8, 256, 192, 3000), (2, 64, 70, 33), (3, 128, 144, 1),
+                                                              (4, 256, 300, 257)])
+def test_split_train_step_vs_fp32_kernels_and_two_launch_path(layers, width, n_samples, n_rays):
+    """afx_train_step_mse for rays that straddle the 256-sample workgroup tiles (the reference's own 300 samples per ray, nerf/run_nerf_acc.py:129;
+    192 = the hierarchical 128 + 64; 70 -> 96 and 144 -> 160 padded): forward half, per-ray reduction, backward half - against the
+    exact-fp32 kernels (render + autograd) and against the path it replaces (forward launch + backward kernel that recomputes the
+    forward, here at the 16-bit-stash f16 precision, which has no split)."""
+    from nerf_for_angiography_amd.render import render_rays, train_step_mse
+    from nerf_for_angiography_amd.engine import RenderSpec
+    torch.manual_seed(layers * 100 + width + n_samples)
+    m = make_model(layers, width, precision="f32")
+    with torch.no_grad():
+        m.output_linear[0].weight.mul_(4.0)
+        m.output_linear[0].bias.fill_(-5.0)
+    o, d, tgt = _ref_iteration_problem(n_rays)
+    o, d, tgt = o.to(DEV), d.to(DEV), tgt.to(DEV)
+    spec = RenderSpec(n_rays=n_rays, n_samples=n_samples, origins=o, dirs=d, mode="acc", t_near=1400.0, t_far=1600.0)
+    out = render_rays(m, o, d, n_samples, 1400.0, 1600.0, mode="acc")
+    torch.nn.functional.mse_loss(out.rgb_map, tgt).backward()
+    pix32 = out.rgb_map.detach().clone()
+    g32 = torch.cat([p.grad.reshape(-1) for p in m._hip_params()]).double()
+    res = {}
+    for prec in ("f16s8", "f16"):
+        m.zero_grad(set_to_none=True)
+        m.precision = prec
+        assert m.engine.fused_step_available(n_samples, prec) == (prec == "f16s8")
+        loss, pix = train_step_mse(m, spec, tgt)
+        res[prec] = (pix, torch.cat([p.grad.reshape(-1) for p in m._hip_params()]).double(), float(loss))
+    assert torch.equal(res["f16s8"][0], res["f16"][0])                      # same forward arithmetic: identical pixels
+    # (optical depths of 3 - 6 at these weights: a pixel's RELATIVE error is its optical depth's ABSOLUTE error, 1e-4 x od; the
+    # 1e-4 pixel bar at benchmark-like transmittances is asserted by the full-size tests)
+    few = n_rays * n_samples < 100000        # (few samples: the bf8 stash rounding has nothing to average over, see test_odd_shapes_vs_oracle)
+    assert rel_l2(res["f16s8"][0].cpu().numpy(), pix32.cpu().numpy()) < (2e-2 if few else 2e-3)
+    e8 = float((res["f16s8"][1] - g32).norm() / g32.norm())
+    e16 = float((res["f16"][1] - g32).norm() / g32.norm())
+    assert e16 < (4 if few else 1) * TOL["f16"]["grad"], e16
+    assert e8 < (0.25 if few else TOL["f16s8"]["grad"]), e8
+    assert abs(res["f16s8"][2] - float(torch.nn.functional.mse_loss(pix32, tgt))) < 1e-3 * res["f16s8"][2] + 1e-7
+
+
+def test_split_train_step_chunking_and_per_ray_depths():
+    """The split step over several ray chunks (chunks hold whole rays: multiples of lcm(s_pad, 256) / 256 tiles) and with the hierarchical
+    pass's per-ray depths (dense convention, 128 + 64 = 192 depths per ray): same gradients as ONE chunk up to the order of the fp32
+    partial sums, bit-identical pixels, and close to the exact-fp32 kernels."""
+    from nerf_for_angiography_amd.render import render_rays, train_step_mse
+    from nerf_for_angiography_amd.engine import RenderSpec
+    n_rays, S = 20000, 192
+    o, d, tgt = _ref_iteration_problem(n_rays, seed=5)
+    o, d, tgt = o.to(DEV), d.to(DEV), tgt.to(DEV)
+    z = torch.sort(1400.0 + 200.0 * torch.rand(n_rays, S, generator=torch.Generator().manual_seed(2)), dim=-1).values.to(DEV)
+    out = {}
+    for ws_mib in (24 << 10, 1500):
+        m = _bench_model("f16s8", seed=3)
+        with torch.no_grad():
+            m.output_linear[0].bias.fill_(-26.0)              # dense convention: the 1e10 tail (SURVEY D3)
+        m.engine.max_workspace_bytes = ws_mib << 20
+        spec = RenderSpec(n_rays=n_rays, n_samples=S, origins=o, dirs=d, mode="dense", z=z)
+        loss, pix = train_step_mse(m, spec, tgt)
+        out[ws_mib] = (pix, torch.cat([p.grad.reshape(-1) for p in m._hip_params()]).double())
+        assert m.engine._ws.numel() <= (ws_mib << 20)
+    assert torch.equal(out[24 << 10][0], out[1500][0])
+    assert float((out[24 << 10][1] - out[1500][1]).norm() / out[1500][1].norm()) < 1e-5
+    m.zero_grad(set_to_none=True)
+    m.precision = "f32"
+    r = render_rays(m, o, d, mode="dense", z=z)
+    torch.nn.functional.mse_loss(r.rgb_map, tgt).backward()
+    g32 = torch.cat([p.grad.reshape(-1) for p in m._hip_params()]).double()
+    assert float(g32.norm()) > 0
+    assert float((out[1500][1] - g32).norm() / g32.norm()) < TOL["f16s8"]["grad"]
+
+
+def test_split_train_step_safe_waits_build_is_bit_identical():
+    """The race detector (libafx_safe.so: every counted wait a full one) on the two half-kernels: 5 625 rays x 300 samples, 8x256."""
+    from nerf_for_angiography_amd import build as afx_build
+    from nerf_for_angiography_amd.engine import Engine, RenderSpec
+    from nerf_for_angiography_amd.render import train_step_mse
+    afx_build.build(variant="safe")
+    o, d, tgt = _ref_iteration_problem(5625, seed=8)
+    spec = RenderSpec(n_rays=5625, n_samples=300, origins=o.to(DEV), dirs=d.to(DEV), mode="acc", t_near=1400.0, t_far=1600.0)
+    res = []
+    for variant in ("", "safe"):
+        m = _bench_model("f16s8", seed=1)
+        m._engine = Engine(256, 8, "none", 0, variant=variant)
+        _, pix = train_step_mse(m, spec, tgt.to(DEV))
+        torch.cuda.synchronize()
+        res.append((pix, torch.cat([p.grad.reshape(-1) for p in m._hip_params()])))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+def test_force_split_matches_fused_kernel_at_full_size(monkeypatch):
+    """AFX_FORCE_SPLIT=1 runs the two half-kernels also where the fused kernel applies (512^2 x 128): same pixels bit for bit, gradients
+    equal up to rounding of the factored output-layer sums (sum g' H x dod instead of sum (dod g') H)."""
+    from nerf_for_angiography_amd.engine import Engine
+    from nerf_for_angiography_amd.render import train_step_mse, projection_spec
+    from nerf_for_angiography_amd.phantomdata.helpers import get_ray_values
+    W, S = 512, 128
+    _, _, m44, _, _ = get_ray_values(24.0, 8.0, 0.0, np.array([0, 0, 1500.0]), W, W, 13.0 * W, "cpu")
+    spec = projection_spec(torch.from_numpy(m44[None]).to(DEV), W, W, 13.0 * W, S, 1400.0, 1600.0)
+    tgt = torch.rand(W * W, generator=torch.Generator().manual_seed(9)).to(DEV)
+    res = []
+    for force in ("0", "1"):
+        monkeypatch.setenv("AFX_FORCE_SPLIT", force)
+        m = _bench_model("f16s8")
+        m._engine = Engine(256, 8, "none", 0)          # the knob is read when the context is created
+        _, pix = train_step_mse(m, spec, tgt)
+        res.append((pix, torch.cat([p.grad.reshape(-1) for p in m._hip_params()]).double()))
+        del m
+    assert torch.equal(res[0][0], res[1][0])
+    assert float((res[0][1] - res[1][1]).norm() / res[0][1].norm()) < 2e-3
+
+
+def test_hierarchical_train_step_fused_pieces_vs_oracle_and_autograd_path():
+    """render.hierarchical_train_step_mse - coarse forward leaving tau[R,S], afx_fine_depths_from_tau (weights formed per ray in the kernel),
+    split-phase fused fine step - against (i) the oracle's fine depths from the oracle's coarse weights and (ii) the operator-by-operator path
+    it replaces (render with want_aux -> fine_sampling -> mse_loss -> backward), at 8x256, 128 + 64 samples."""
+    from oracle import angio_oracle as orc
+    from nerf_for_angiography_amd.render import render_rays, hierarchical_train_step_mse
+    from nerf_for_angiography_amd.nerf.nerf_helpers import fine_sampling
+    from nerf_for_angiography_amd.engine import fine_depths_from_tau, RenderSpec
+    o, d, z, u, tgt, SC, NF = _c3_setup(4096)
+    od, dd, zd, ud, td = o.to(DEV), d.to(DEV), z.to(DEV), u.to(DEV), tgt.to(DEV)
+    m = _bench_model("f16s8", seed=5)
+    with torch.no_grad():
+        m.output_linear[0].bias.fill_(-26.0)
+    # (i) depths: tau from the exact-fp32 kernels -> in-kernel weights -> sample_pdf / merge, vs the oracle on 256 of the rays
+    m.precision = "f32"
+    with torch.no_grad():
+        _, _, tau = m.engine.render_forward(m._prepared(), RenderSpec(
+            n_rays=4096, n_samples=SC, origins=od, dirs=dd, mode="dense", z=zd), "f32", want_tau=True)
+        zf = fine_depths_from_tau(zd, tau, ud)
+    cfg = dict(num_early_layers=8, num_filters=256)
+    params = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        raw_c = orc.cppn_forward(orc.points_dense(o[:256], d[:256], z).reshape(-1, 3), cfg, params).reshape(256, SC, 1)
+        _, _, w_c, _, _ = orc.render_volume_density(raw_c, d[:256], z)
+        zf_c = orc.fine_depths(z, w_c, u[:256], 256)
+    same = (zf[:256].cpu() - zf_c).abs().max(-1).values < 1e-2
+    assert float(same.float().mean()) > 0.97
+    assert rel_l2(zf[:256].cpu()[same].numpy(), zf_c[same].numpy()) < 1e-6
+    # (ii) the fused step vs the operator path, both at f16s8 / f16 arithmetic
+    m.precision = "f16s8"
+    loss, pix, z_all = hierarchical_train_step_mse(m, od, dd, zd, NF, td, u=ud)
+    g_fused = torch.cat([p.grad.reshape(-1) for p in m._hip_params()]).double()
+    m.zero_grad(set_to_none=True)
+    with torch.no_grad():
+        coarse = render_rays(m, od, dd, mode="dense", z=zd, want_aux=True)
+    rgb, _, _ = fine_sampling(zd, coarse.weights, od, dd, m, None, NF, 131072, u=ud)
+    torch.nn.functional.mse_loss(rgb, td).backward()
+    g_ops = torch.cat([p.grad.reshape(-1) for p in m._hip_params()]).double()
+    assert float(g_ops.norm()) > 0
+    agree = (z_all - torch.sort(z_all, -1).values).abs().max() == 0
+    assert bool(agree)
+    assert rel_l2(pix.cpu().numpy(), rgb.detach().cpu().numpy()) < 2e-3
+    assert float((g_fused - g_ops).norm() / g_ops.norm()) < 2 * TOL["f16s8"]["grad"]

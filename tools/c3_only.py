@@ -38,8 +38,12 @@ o, d = o.reshape(-1, 3).float().contiguous(), d.reshape(-1, 3).float().contiguou
 tgt = torch.rand(W * W, device=dev); z = torch.linspace(1400.0, 1600.0, SC, device=dev)
 PROF = not os.environ.get("NOPROF")
 m.engine.profile(PROF)
+from nerf_for_angiography_amd.render import hierarchical_train_step_mse
 def step3():
     opt.zero_grad(set_to_none=True)
+    if os.environ.get("FUSED"):      # coarse forward -> in-kernel weights / sample_pdf / merge -> split-phase fused fine step
+        hierarchical_train_step_mse(m, o, d, z, NF, tgt); opt.step()
+        return
     with torch.no_grad():
         coarse = render_rays(m, o, d, mode="dense", z=z, want_aux=True)
     rgb, dep, ent = fine_sampling(z, coarse.weights, o, d, m, None, NF, 131072)

@@ -23,7 +23,8 @@ def main():
     ap.add_argument("--iters", type=int, default=20000)
     ap.add_argument("--rays", type=int, default=8192)
     ap.add_argument("--eval-every", type=int, default=2500)
-    ap.add_argument("--lr", type=float, default=5e-4)
+    ap.add_argument("--lr", type=float, default=1e-4, help="the reference's learning rate (nerf/run_nerf_acc.py:147)")
+    ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--precisions", default="f32,f16,f16s8")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
@@ -58,15 +59,15 @@ def main():
               num_img=1, device=dev)
     out = {"config": {"geometry": "C2: 256x256, 30 training views + 1 held-out, 64 samples/ray, acc convention", "model": "8x256 ReLU CPPN",
                       "rays_per_iteration": args.rays, "iterations": args.iters, "lr": f"{args.lr} x 0.1^(it/iters), Adam",
-                      "targets": "afx_project_volume of the 192^3 voxelised capsule tree, 160 samples", "seed": 0}, "runs": {}}
+                      "targets": "afx_project_volume of the 192^3 voxelised capsule tree, 160 samples", "seed": args.seed}, "runs": {}}
     grids = {}
     for prec in args.precisions.split(","):
-        torch.manual_seed(0)
+        torch.manual_seed(args.seed)
         m = CPPN(dict(md, precision=prec)).to(dev)
         with torch.no_grad():
             m.output_linear[0].bias.fill_(-5.0)
         opt = torch.optim.Adam(list(m.parameters()), lr=args.lr)
-        gen = torch.Generator().manual_seed(1234)
+        gen = torch.Generator().manual_seed(1234 + args.seed)
         hist = []
         t0 = time.time()
         for it in range(args.iters + 1):

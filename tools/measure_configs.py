@@ -68,6 +68,11 @@ def step3():
     rgb, dep, ent = fine_sampling(z, coarse.weights, o, d, m, None, NF, 131072)
     torch.nn.functional.mse_loss(rgb, tgt).backward(); opt.step()
 t = timeit(step3)
+m.engine.profile(True)
+t_again = timeit(step3, warm=0, steps=3)
+kern = {k: round(m.engine.profile_read(k)[0] / 3, 2) for k in ("chain_fwd", "chain_bwd", "wgrad")}
+m.engine.profile(False)
+print("C3 again (profiled):", round(t_again * 1e3, 2), kern, "workspace at 0x%x, %.1f GiB" % (m.engine._ws.data_ptr(), m.engine._ws.numel() / 2**30), flush=True)
 out["C3 512^2x(128 coarse + 192 fine)"] = dict(ms_per_step=round(t * 1e3, 2), ray_samples_per_s=round(W * W * (SC + SC + NF) / t / 1e6, 1))
 print("C3", out["C3 512^2x(128 coarse + 192 fine)"], flush=True)
 # forward-only renders (evaluation): split-bf16 and bf16
