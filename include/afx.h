@@ -64,15 +64,23 @@ enum { AFX_ENC_NONE = 0, AFX_ENC_BARF = 1, AFX_ENC_FOURIER = 2 };
  *            (afx_mlp_backward) runs exactly as F16.                           */
 enum { AFX_PREC_F32 = 0, AFX_PREC_BF16X3 = 1, AFX_PREC_BF16 = 2, AFX_PREC_F16 = 3, AFX_PREC_F16S8 = 4 };
 
-/* CPPN(model_definition) — model/CPPN.py:10-139.  Only the configuration
- * nerf/run_nerf_acc.py:168-183 builds is accelerated: ReLU, no skip block,
- * no view-direction head, one output channel. */
+/* CPPN(model_definition) — model/CPPN.py:10-139.  The configuration
+ * nerf/run_nerf_acc.py:168-183 builds is accelerated end to end (ReLU, no skip block,
+ * no view-direction head, one output channel); tanh / sine variants of it in the forward direction. */
+/* act_func of the hidden layers (model/CPPN.py:53-60).  ReLU is what nerf/run_nerf_acc.py trains and what every kernel takes.
+ * tanh and sine (Sine(w0) on the first layer, Sine() behind it, CPPN.py:278-300) are evaluated by the FORWARD entry points
+ * (afx_mlp_infer, afx_render_forward: inference, evaluation renders, density grids; without an input encoding); the backward entry points return
+ * AFX_E_INVALID for them - a tanh / sine backward needs the activation VALUES per element, not a 1-bit mask. */
+enum { AFX_ACT_RELU = 0, AFX_ACT_TANH = 1, AFX_ACT_SINE = 2 };
+
 typedef struct afx_model_desc {
   int32_t n_in;        /* num_input_channels (3)                              */
   int32_t enc;         /* AFX_ENC_*                                           */
   int32_t n_freq;      /* pos_enc_basis L (ignored for AFX_ENC_NONE)          */
   int32_t width;       /* num_filters: 64, 128 or 256                         */
   int32_t n_hidden;    /* num_early_layers N  (Linear count = N + 2)          */
+  int32_t act;         /* AFX_ACT_*                                           */
+  float act_w0;        /* AFX_ACT_SINE: sine_weights (first-layer frequency factor); ignored otherwise */
 } afx_model_desc;
 
 /* Flat fp32 parameter buffer layout (same order as the state-dict of the
@@ -169,6 +177,23 @@ int afx_render_forward(afx_ctx* ctx, int prec, const void* prepared, const afx_r
  * the weight-gradient contraction over samples). */
 int afx_render_backward(afx_ctx* ctx, int prec, const void* prepared, const afx_render_args* args,
                         const float* dL_dpixel, float* grad_flat, void* stream);
+
+/* ---- The reference's own iteration body on packed samples (nerf/run_nerf_acc.py:287-306): after the occupancy-grid march
+ * (afx_march_* -> packed, ray-sorted t_starts / t_ends, offsets[R+1]) the reference gathers positions, evaluates the MLP (get_predictions),
+ * multiplies the per-ray transmittances (acc_render_volume_density), takes the MSE and backpropagates.  afx_train_step_packed_mse does
+ * all of that as the split-phase training step (forward half / per-ray reduction / backward half, see afx_train_step_mse) on a
+ * GROUP-ALIGNED copy of the list: ray r's samples start at padded index 32 * group_offsets[r] (group_offsets = exclusive scan of
+ * ceil(count_r / 32), int64 [R+1], the caller's cumsum), the tail of its last 32-sample group is dead padding (t_end <= t_start),
+ * group_ray[g] = r - so a wavefront's 32 samples always belong to one ray.  afx_pack_groups builds ts_pad / te_pad / group_ray.
+ * pixel[r] = prod exp(-sigmoid(raw) (t_e - t_s)) (1 for a ray without samples), L = inv_n sum_r (pixel_r - target_r)^2, grad_flat += dL/dparams.
+ * AFX_PREC_F16S8 without an input encoding; the workspace (AFX_Q_BWD_WORKSPACE_FULL with arg0 = n_rays, arg1 = 32 * n_groups / n_rays rounded up,
+ * or simply arg0 = 0, arg1 = 32 * n_groups plus n_rays + n_groups floats) must hold the whole list in one chunk. */
+int afx_pack_groups(const int64_t* offsets, const int64_t* group_offsets, int64_t n_rays, const float* t_starts, const float* t_ends,
+                    float* ts_pad, float* te_pad, int32_t* group_ray, void* stream);
+int afx_train_step_packed_mse(afx_ctx* ctx, int prec, const void* prepared, const float* origins, const float* dirs, int64_t n_rays,
+                              const int64_t* group_offsets, const int32_t* group_ray, int64_t n_groups, const float* ts_pad,
+                              const float* te_pad, const float* target, float inv_n, float* pixel, float* grad_flat,
+                              void* workspace, size_t workspace_bytes, void* stream);
 
 /* One fused training pass over a ray batch — the body of nerf/run_nerf_acc.py:287-306 (render, mse_loss,
  * backward) without materialising anything between the steps: the backward kernel's forward recompute IS the

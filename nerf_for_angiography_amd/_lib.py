@@ -6,6 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libafx.so")
 
+ACT = {"relu": 0, "tanh": 1, "sine": 2}
 ENC = {"none": 0, "barf": 1, "fourier": 2}
 PREC = {"f32": 0, "bf16x3": 1, "bf16": 2, "f16": 3, "f16s8": 4}
 RAYS_ARRAYS, RAYS_POSE = 0, 1
@@ -19,7 +20,7 @@ class AfxError(RuntimeError):
 
 class ModelDesc(C.Structure):
     _fields_ = [("n_in", C.c_int32), ("enc", C.c_int32), ("n_freq", C.c_int32), ("width", C.c_int32),
-                ("n_hidden", C.c_int32)]
+                ("n_hidden", C.c_int32), ("act", C.c_int32), ("act_w0", C.c_float)]
 
 
 class RenderArgs(C.Structure):
@@ -80,6 +81,9 @@ _SIGS = {
     "afx_grid_update": (C.c_int, [C.POINTER(GridDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_float, C.c_void_p]),
     "afx_grid_binarize": (C.c_int, [C.POINTER(GridDesc), C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "afx_grid_pack": (C.c_int, [C.POINTER(GridDesc), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "afx_pack_groups": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "afx_train_step_packed_mse": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "afx_march_count": (C.c_int, [C.POINTER(MarchArgs), C.c_void_p, C.c_void_p]),
     "afx_march_write": (C.c_int, [C.POINTER(MarchArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "afx_march_visibility": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,

@@ -28,9 +28,12 @@ AFX_CHAIN16_FWD(AFX_CHAIN16_HERE, 128) AFX_CHAIN16_BWD(AFX_CHAIN16_HERE, 128)
 AFX_CHAIN16_FWD(AFX_CHAIN16_HERE, 256) AFX_CHAIN16_BWD(AFX_CHAIN16_HERE, 256)
 #ifdef AFX_SINGLE_TU
 #define AFX_CHAIN16_PH_HERE AFX_CHAIN16_PH_DEF
+#define AFX_CHAIN16_ACT_HERE AFX_CHAIN16_ACT_DEF
 #else
 #define AFX_CHAIN16_PH_HERE AFX_CHAIN16_PH_DECL
+#define AFX_CHAIN16_ACT_HERE AFX_CHAIN16_ACT_DECL
 #endif
+AFX_CHAIN16_ACTS(AFX_CHAIN16_ACT_HERE, 64) AFX_CHAIN16_ACTS(AFX_CHAIN16_ACT_HERE, 128) AFX_CHAIN16_ACTS(AFX_CHAIN16_ACT_HERE, 256)
 AFX_CHAIN16_PHASES(AFX_CHAIN16_PH_HERE, 64) AFX_CHAIN16_PHASES(AFX_CHAIN16_PH_HERE, 128) AFX_CHAIN16_PHASES(AFX_CHAIN16_PH_HERE, 256)
 
 using namespace afx;
@@ -141,8 +144,11 @@ extern "C" int afx_create(const afx_model_desc* d, afx_ctx** out) {
   if (d->enc < AFX_ENC_NONE || d->enc > AFX_ENC_FOURIER) return fail(AFX_E_INVALID, "afx_create: bad enc %d", d->enc);
   if (d->enc != AFX_ENC_NONE && (d->n_freq < 1 || d->n_freq > 10))
     return fail(AFX_E_INVALID, "afx_create: n_freq must be in 1..10 (got %d)", d->n_freq);
+  if (d->act < AFX_ACT_RELU || d->act > AFX_ACT_SINE) return fail(AFX_E_INVALID, "afx_create: bad act %d", d->act);
+  if (d->act != AFX_ACT_RELU && d->enc != AFX_ENC_NONE) return fail(AFX_E_INVALID, "afx_create: tanh / sine models are taken without an input encoding only");
   afx_ctx* c = new afx_ctx();
   c->d = *d;
+  if (d->act != AFX_ACT_SINE) c->d.act_w0 = 1.f;
   if (d->enc == AFX_ENC_NONE) c->d.n_freq = 0;
   c->k0 = 3 + 6 * c->d.n_freq;
   c->nq = (c->k0 + 1) / 2;
@@ -366,6 +372,11 @@ template <int F>
 static int launch_chain_f(afx_ctx* c, int prec, bool bwd, const ChainArgs& a, size_t lds, int grid, hipStream_t st, int phase) {
   const int which = bwd ? AFX_K_CHAIN_BWD : AFX_K_CHAIN_FWD;
   const bool enc = c->d.enc != AFX_ENC_NONE;
+  if (!bwd && a.act != 0 && prec != AFX_PREC_F32) {      // tanh / sine: the forward-only kernels with the activation epilogue
+    if (prec == AFX_PREC_BF16X3) return launch_chain_k(c, k_chain_bf16<F, true, false, false, 4, false, false, false, 0, 1>, which, a, lds, grid, st);
+    if (is_f16(prec)) return launch_chain_k(c, k_chain_bf16<F, false, false, false, 8, false, true, false, 0, 1>, which, a, lds, grid, st, 512);
+    return launch_chain_k(c, k_chain_bf16<F, false, false, false, 8, false, false, false, 0, 1>, which, a, lds, grid, st, 512);
+  }
   if (phase == 1) return launch_chain_k(c, k_chain_bf16<F, false, false, true, 8, true, true, true, 1>, which, a, lds, grid, st, 512);
   if (phase == 2) return launch_chain_k(c, k_chain_bf16<F, false, false, true, 8, true, true, true, 2>, which, a, lds, grid, st, 512);
   if (prec == AFX_PREC_F32)
@@ -421,6 +432,7 @@ static void fill_model(const afx_ctx* c, int prec, bool bwd, const void* prepare
   // the backward kernel of the split mode recomputes in plain bf16: it streams only the hi parts
   if (is_bf16(prec)) a.slot_bytes = chain_slot_bytes(c->nt, nk0_of(c), bwd, prec == AFX_PREC_BF16X3 && !bwd);
   a.n_hidden = c->d.n_hidden; a.k0 = c->k0; a.nq = c->nq; a.enc = c->d.enc; a.n_freq = c->d.n_freq;
+  a.act = c->d.act; a.act_w0 = c->d.act_w0;
   a.persistent = 1;
 }
 
@@ -565,8 +577,10 @@ static int launch_wgrad8_t(afx_ctx* c, const WgradArgs& w, const ReduceArgs& rd,
 // `split` (fused MSE step whose rays straddle tiles): the chain runs as PHASE 1, per-ray finish (pixel, dL/d(optical depth)), PHASE 2 -
 // a.dod / a.od_part / a.target / a.pixel / a.inv_n are set by the caller; chunks hold whole rays.
 static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws, size_t ws_bytes, float* grad_flat, hipStream_t st,
-                        bool split = false, int64_t n_rays = 0) {
+                        bool split = false, int64_t n_rays = 0, const int64_t* goff = nullptr) {
   const int F = c->d.width, N = c->d.n_hidden;
+  if (c->d.act != AFX_ACT_RELU)
+    return fail(AFX_E_INVALID, "backward: tanh / sine models are forward-only in this library (train them through the module's PyTorch operators)");
   BwdLayout B = bwd_layout(c, prec, 0);
   const size_t fixed = head + B.fixed_bytes;
   const int TILE = bwd_tile(prec);
@@ -600,6 +614,8 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
     const int64_t n_chunks = (tiles + chunk - 1) / chunk;
     chunk = (tiles + n_chunks - 1) / n_chunks;
   }
+  if (split && goff && chunk < tiles)      // packed samples: rays straddle tiles anywhere, the per-ray reduction needs the whole list
+    return fail(AFX_E_WORKSPACE, "packed training step: the workspace must hold all %lld tiles in one chunk (%lld fit)", (long long)tiles, (long long)chunk);
   if (split && chunk < tiles) {
     if (chunk < ray_tiles) return fail(AFX_E_WORKSPACE, "backward workspace too small for one group of whole rays (%lld tiles)", (long long)ray_tiles);
     chunk = chunk / ray_tiles * ray_tiles;
@@ -670,8 +686,12 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
       int64_t ray1 = t1 * TILE / a.s_pad;
       if (ray1 > n_rays || t1 == tiles) ray1 = n_rays;
       const int gpr = a.s_pad / GROUP;
-      hipLaunchKernelGGL(k_finish_mse, dim3((unsigned)((ray1 - ray0 + 255) / 256)), dim3(256), 0, st, (const float*)a.od_part + ray0 * gpr, gpr,
-                         ray1 - ray0, a.target + ray0, a.inv_n, a.pixel + ray0, (float*)a.dod + ray0);
+      if (goff)
+        hipLaunchKernelGGL(k_finish_mse_packed, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, st, (const float*)a.od_part, goff, n_rays, a.target,
+                           a.inv_n, a.pixel, (float*)a.dod);
+      else
+        hipLaunchKernelGGL(k_finish_mse, dim3((unsigned)((ray1 - ray0 + 255) / 256)), dim3(256), 0, st, (const float*)a.od_part + ray0 * gpr, gpr,
+                           ray1 - ray0, a.target + ray0, a.inv_n, a.pixel + ray0, (float*)a.dod + ray0);
       rc = launch_chain(c, prec, true, p, st, 2);
     } else rc = launch_chain(c, prec, true, a, st);
     if (rc) return rc;
@@ -697,7 +717,7 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
     w.rows_per_split = (int)rps;
     w.partial = partial; w.partial2 = partial2; w.partial_s = partial_s; w.debug = a.debug; w.small_groups = sg ? 1 : 0;
     w.gmax = a.gmax; w.stash_esz = (int)esz; w.gexp = a.gexp; w.enc16 = enc16 ? 1 : 0; w.coef_cols = a.coef_cols;
-    w.dod = split ? a.dod : nullptr; w.gpr = a.s_pad / GROUP; w.group0 = t0 * (TILE / GROUP);
+    w.dod = split ? a.dod : nullptr; w.gpr = a.s_pad / GROUP; w.group0 = t0 * (TILE / GROUP); w.group_ray = goff ? a.group_ray : nullptr;
     ReduceArgs rd;
     rd.partial = partial; rd.partial2 = partial2; rd.n_hidden = N; rd.k0 = c->k0; rd.k0pad = k0ld; rd.n_splits = splits;
     rd.grad = grad_flat; rd.hidden_only = b16 ? 1 : 0; rd.partial_s = partial_s;
@@ -770,6 +790,48 @@ extern "C" int afx_train_step_mse(afx_ctx* c, int prec, const void* prepared, co
     head = dod_bytes + od_bytes;
   }
   return run_backward(c, prec, a, head, (char*)r->workspace, r->workspace_bytes, grad_flat, (hipStream_t)stream, do_split, r->n_rays);
+}
+
+extern "C" int afx_pack_groups(const int64_t* offsets, const int64_t* group_offsets, int64_t n_rays, const float* t_starts, const float* t_ends,
+                               float* ts_pad, float* te_pad, int32_t* group_ray, void* stream) {
+  if (n_rays <= 0) return AFX_OK;
+  if (!offsets || !group_offsets || !ts_pad || !te_pad || !group_ray) return fail(AFX_E_INVALID, "afx_pack_groups: null argument");
+  hipLaunchKernelGGL(k_pack_groups, dim3((unsigned)((n_rays + 63) / 64)), dim3(64), 0, (hipStream_t)stream, offsets, group_offsets, n_rays, t_starts, t_ends,
+                     ts_pad, te_pad, group_ray);
+  HIPCHK(hipGetLastError());
+  return AFX_OK;
+}
+
+extern "C" int afx_train_step_packed_mse(afx_ctx* c, int prec, const void* prepared, const float* origins, const float* dirs, int64_t n_rays,
+                                         const int64_t* group_offsets, const int32_t* group_ray, int64_t n_groups, const float* ts_pad,
+                                         const float* te_pad, const float* target, float inv_n, float* pixel, float* grad_flat,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
+  if (!c || !prepared || !origins || !dirs || !group_offsets || !target || !pixel || !grad_flat || !workspace)
+    return fail(AFX_E_INVALID, "afx_train_step_packed_mse: null argument");
+  if (n_rays <= 0) return AFX_OK;
+  if (n_groups < 0 || n_groups * 32 > ((int64_t)1 << 31) - 256) return fail(AFX_E_INVALID, "afx_train_step_packed_mse: n_groups out of range");
+  if (prec != AFX_PREC_F16S8 || c->d.enc != AFX_ENC_NONE || !c->small_in_kernel)
+    return fail(AFX_E_INVALID, "afx_train_step_packed_mse: AFX_PREC_F16S8 without an input encoding only");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t dod_bytes = rup64((size_t)n_rays * 4, 256), od_bytes = rup64((size_t)std::max<int64_t>(n_groups, 1) * 4, 256);
+  if (workspace_bytes < dod_bytes + od_bytes) return fail(AFX_E_WORKSPACE, "afx_train_step_packed_mse: workspace too small");
+  float* dod = (float*)workspace;
+  float* od_part = (float*)((char*)workspace + dod_bytes);
+  if (n_groups == 0) {      // nothing survived the march: every pixel is the empty product, no gradient (the reference skips the step, :293)
+    hipLaunchKernelGGL(k_finish_mse_packed, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, st, (const float*)od_part, group_offsets, n_rays, target,
+                       inv_n, pixel, dod);
+    HIPCHK(hipGetLastError());
+    return AFX_OK;
+  }
+  if (!group_ray || !ts_pad || !te_pad) return fail(AFX_E_INVALID, "afx_train_step_packed_mse: null argument");
+  ChainArgs a = {};
+  fill_model(c, prec, true, prepared, a);
+  a.mode = 1; a.org = origins; a.dir = dirs; a.poses = nullptr;
+  a.depth_mode = 4; a.z = ts_pad; a.te = te_pad; a.group_ray = group_ray;
+  a.n_samples = GROUP; a.s_pad = GROUP; a.n_total = n_groups * GROUP;
+  a.fused = 1; a.target = target; a.pixel = pixel; a.inv_n = inv_n;
+  a.dod = dod; a.od_part = od_part;
+  return run_backward(c, prec, a, dod_bytes + od_bytes, (char*)workspace, workspace_bytes, grad_flat, st, true, n_rays, group_offsets);
 }
 
 extern "C" int afx_mlp_backward(afx_ctx* c, int prec, const void* prepared, const float* pts, int64_t n_pts,

@@ -22,6 +22,12 @@
   extern template __global__ void k_chain_bf16<F, X3, ENC, BWD, NW, SG, H16, S8>(const afx::ChainArgs);
 #define AFX_CHAIN16_DEF(F, X3, ENC, BWD, NW, SG, H16, S8) \
   template __global__ void k_chain_bf16<F, X3, ENC, BWD, NW, SG, H16, S8>(const afx::ChainArgs);
+// forward-only kernels for tanh / sine models: split bf16, bf16, f16
+#define AFX_CHAIN16_ACTS(X, F) X(F, true, 4, false) X(F, false, 8, false) X(F, false, 8, true)
+#define AFX_CHAIN16_ACT_DECL(F, X3, NW, H16) \
+  extern template __global__ void k_chain_bf16<F, X3, false, false, NW, false, H16, false, 0, 1>(const afx::ChainArgs);
+#define AFX_CHAIN16_ACT_DEF(F, X3, NW, H16) \
+  template __global__ void k_chain_bf16<F, X3, false, false, NW, false, H16, false, 0, 1>(const afx::ChainArgs);
 // split phases of the 8-bit-stash training kernel (PHASE 1 = forward half, 2 = backward half)
 #define AFX_CHAIN16_PHASES(X, F) X(F, 1) X(F, 2)
 #define AFX_CHAIN16_PH_DECL(F, PH) \

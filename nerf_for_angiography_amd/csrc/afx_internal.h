@@ -82,6 +82,12 @@ struct ChainArgs {
   int32_t stash8;           // f16 mode: 8-bit (bf8) stash of H_l and dZ'_l
   int32_t* gexp;            // 8-bit stash: power-of-two exponent of each 32-sample group's largest |dL/draw| [rows/32]
   int32_t coef_cols;        // 3*n_freq when the fourier coefficients train (the chain kernel then also stashes d(enc)/d(coef)/(2 pi)), else 0
+  // packed, group-aligned samples (AFX_DEPTH_PACKED = 4: the occupancy-grid march's output): sample n of the padded list belongs to ray
+  // group_ray[n >> 5]; its interval is [z[n], te[n]) (dead padding slots: te <= ts); optical-depth partials are indexed by group
+  const float* te;
+  const int32_t* group_ray;
+  int32_t act;              // activation of the hidden layers: 0 ReLU (every kernel), 1 tanh, 2 sine (forward-only kernels)
+  float act_w0;             // sine: the first layer's frequency factor w0 (model/CPPN.py:53-57)
   // split phases of the 8-bit-stash training kernel (rays that straddle workgroup tiles)
   char* masks;              // [tiles of the chunk][(N+1) x NT x 512 x u16]: the ReLU-mask LDS image of each tile (PHASE 1 writes, PHASE 2 reads)
   float* gpart;             // [rows] g' = dt sigma (1 - sigma) of each sample (PHASE 1 writes, PHASE 2 reads)
@@ -109,6 +115,7 @@ struct WgradArgs {
   int32_t coef_cols;        // 3*n_freq when the fourier coefficients train, else 0
   // split phases: the output-layer group sums were formed with g' (without the ray's dL/d(optical depth)); k_small_from_groups applies it
   const float* dod;         // [n_rays] or null (fused kernel: the sums already carry it)
+  const int32_t* group_ray; // packed samples: ray of each group (then dod[group_ray[g]]), else null (dod[(group0 + g) / gpr])
   int32_t gpr;              // 32-sample groups per ray (s_pad / 32)
   int64_t group0;           // global index of the chunk's first group
 };

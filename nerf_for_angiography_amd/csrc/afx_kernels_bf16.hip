@@ -225,9 +225,12 @@ template <int K> __device__ __forceinline__ void lds_wait_frag(u32x4& r) {
 // factor common to a group, applied by k_small_from_groups); after the per-ray reduction (k_finish_mse: pixel, dL/d(optical depth))
 // PHASE 2, the backward half, loads the masks back into LDS by LDS-DMA and runs the input-gradient chain with g = dod[ray] g'.
 // Nothing is computed twice (the two-launch path it replaces rendered the forward, then recomputed it inside the backward kernel).
-template <int F, bool X3, bool ENC, bool BWD, int NW, bool SG = false, bool H16 = false, bool S8 = false, int PHASE = 0>
+// ACTV = 1: the forward-only kernels for tanh / sine models (a.act): the activation is applied to the accumulator in the epilogue instead of
+// the packed-ReLU steps.  Separate instantiations, so that the ReLU kernels stay exactly the code they were.
+template <int F, bool X3, bool ENC, bool BWD, int NW, bool SG = false, bool H16 = false, bool S8 = false, int PHASE = 0, int ACTV = 0>
 __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs a) {
   static_assert(PHASE == 0 || (S8 && !ENC && PHASE <= 2), "split phases: the 8-bit-stash kernel without an input encoding");
+  static_assert(ACTV == 0 || (!BWD && !ENC), "tanh / sine: forward-only kernels without an input encoding");
   constexpr bool P1 = PHASE == 1, P2 = PHASE == 2;
   static_assert(!S8 || (SG && H16), "8-bit stash: f16 backward kernel with in-kernel small gradients");
   static_assert(!SG || (BWD && !X3 && (!ENC || S8)), "in-kernel small gradients: plain backward kernel; with an encoding only the 8-bit-stash kernel");
@@ -447,6 +450,12 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
     // (bl, bt >= 0: once the accumulator has been consumed it is reloaded with the bias of the tile this wave computes
     // next, so that the LDS latency of the reload hides behind the rest of the epilogue instead of in front of the MFMAs)
     auto epilogue = [&](int l, int t, f32x16& acc, int cg, u32x4* nf, u32x4* nl, int bl = -1, int bt = -1) {
+      // tanh / sine models (forward-only kernels): the activation is applied to the accumulator, the ReLU steps below are skipped
+      constexpr bool relu = ACTV == 0;
+      if constexpr (!relu) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = act_value(acc[j], a.act, l == 0 ? a.act_w0 : 1.f);
+      }
       if (l == N) {       // the output layer (width -> 1) reads the fp32 activations
         asm volatile("" ::: "memory");      // keeps hipcc from hoisting the w_out reads (and their lgkmcnt(0)) into every layer's epilogue
         const f32x4* wp = (const f32x4*)(wout_perm + (hh * NT + t) * 16);
@@ -455,20 +464,23 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
           const f32x4 w4 = wp[q];
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            dot[cg] = fmaf(__int_as_float(max(__float_as_int(acc[4 * q + e]), 0)), w4[e], dot[cg]);
+            dot[cg] = fmaf(relu ? __int_as_float(max(__float_as_int(acc[4 * q + e]), 0)) : acc[4 * q + e], w4[e], dot[cg]);
         }
       }
       if constexpr (X3) {
         float v[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = __int_as_float(max(__float_as_int(acc[j]), 0));
+        for (int j = 0; j < 16; ++j) v[j] = relu ? __int_as_float(max(__float_as_int(acc[j]), 0)) : acc[j];
         split_frag(v, nf[0], nl[0]);
         split_frag(v + 8, nf[1], nl[1]);
       } else {
         // round to bf16 first, ReLU on the packed pairs (rounding is monotone and keeps the sign: same result)
         unsigned p[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) p[q] = relu2(pack2t<H16>(acc[2 * q], acc[2 * q + 1]));
+        for (int q = 0; q < 8; ++q) {
+          p[q] = pack2t<H16>(acc[2 * q], acc[2 * q + 1]);
+          if (relu) p[q] = relu2(p[q]);
+        }
         if (bt >= 0) acc = bias_init(bl, bt);
         if (BWD && !(GAPS && (l >= 1 || t == NT - 1))) {
           unsigned bits = nz2(p[0], one2);
@@ -737,7 +749,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
           for (int sh = 16; sh >= 1; sh >>= 1) od += __shfl_xor(od, sh);
           if (lane == 0 && n[cg] < a.n_total) {
             const int gpr = a.s_pad / GROUP;
-            a.od_part[(int64_t)sp[cg].ray * gpr + (n[cg] - sp[cg].ray * a.s_pad) / GROUP] = od;
+            if (a.depth_mode == 4) a.od_part[n[cg] >> 5] = od;      // packed samples: one partial per group of the padded list
+            else a.od_part[(int64_t)sp[cg].ray * gpr + (n[cg] - sp[cg].ray * a.s_pad) / GROUP] = od;
           }
           if constexpr (P1) {      // g' of the sample: everything of dL/draw but the ray's dL/d(optical depth)
             g[cg] = sp[cg].live ? sp[cg].dt * (sig * (1.f - sig)) : 0.f;
@@ -1453,7 +1466,7 @@ __global__ void __launch_bounds__(F) k_small_from_groups(const WgradArgs a) {
   for (int64_t g = g0; g < g1; ++g) {
     const float* rec = base + g * RS;
     // (split phases: SW and sum g were formed with g' = g / dod[ray]; a group never straddles rays)
-    const float ds = a.dod ? a.dod[(a.group0 + g) / a.gpr] : 1.f;
+    const float ds = a.dod ? a.dod[a.group_ray ? (int64_t)a.group_ray[a.group0 + g] : (a.group0 + g) / a.gpr] : 1.f;
     const float sw = rec[p] * ds;
     if (a.enc16) {          // encoded inputs: only the output layer's sums are in the records (first layer: k_wgrad_s8)
       aw += sw;

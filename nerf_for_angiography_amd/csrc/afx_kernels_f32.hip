@@ -99,6 +99,12 @@ __device__ __forceinline__ float enc_dcoef(int k, float px, float py, float pz, 
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
+// Hidden-layer activation other than ReLU (CPPN act_func 'tanh' / 'sine', model/CPPN.py:53-60,278-300), forward-only kernels:
+// act 1 = tanh(z), act 2 = sin(w z) with w = w0 on the first layer and 1 behind it.  (ReLU is the integer fast path at the call sites.)
+__device__ __forceinline__ float act_value(float z, int act, float w) {
+  return act == 1 ? tanhf(z) : enc_sincos(__fmul_rn(w, z), false);
+}
+
 // Per-lane description of the sample a lane's column holds.
 struct Sample {
   float px, py, pz;   // query point
@@ -173,6 +179,21 @@ __device__ __forceinline__ Sample make_sample(const ChainArgs& a, int64_t n) {
     sp.live = true;
     return sp;
   }
+  if (a.depth_mode == 4) {
+    // packed group-aligned samples of the grid march: interval [ts, te) of ray group_ray[n / 32], evaluated at its mid-point exactly as
+    // the reference forms its positions, o + d (t_s + t_e) / 2 (nerf/run_nerf_acc.py:290-292); padding slots (te <= ts) are dead
+    const int r = a.group_ray[n >> 5];
+    const float ts = a.z[n], te = a.te[n];
+    sp.ray = r; sp.s = (int)n; sp.live = te > ts;
+    float ox, oy, oz, dx, dy, dz;
+    load_ray(a, r, ox, oy, oz, dx, dy, dz);
+    const float q = __fadd_rn(ts, te);
+    sp.px = __fadd_rn(ox, __fmul_rn(dx, q) * 0.5f);
+    sp.py = __fadd_rn(oy, __fmul_rn(dy, q) * 0.5f);
+    sp.pz = __fadd_rn(oz, __fmul_rn(dz, q) * 0.5f);
+    sp.dt = sp.live ? __fsub_rn(te, ts) : 0.f;
+    return sp;
+  }
   const int r = (int)(n / a.s_pad);
   int s = (int)(n - (int64_t)r * a.s_pad);
   sp.ray = r;
@@ -218,7 +239,9 @@ __device__ __forceinline__ Sample make_sample(const ChainArgs& a, int64_t n) {
 __device__ __forceinline__ void ray_param(const ChainArgs& a, const Sample& sp, float& t, float& dx, float& dy, float& dz) {
   float ox, oy, oz;
   load_ray(a, sp.ray, ox, oy, oz, dx, dy, dz);
-  if (a.depth_mode == 0) {
+  if (a.depth_mode == 4) {
+    t = __fadd_rn(a.z[sp.s], a.te[sp.s]) * 0.5f;      // (packed: sp.s is the sample's index in the padded list)
+  } else if (a.depth_mode == 0) {
     const float ts = __fadd_rn(a.t_near, __fmul_rn((float)sp.s, a.t_step));
     t = __fadd_rn(ts, __fadd_rn(ts, a.t_step)) * 0.5f;
   } else if (a.depth_mode == 3) {
@@ -309,6 +332,11 @@ __global__ void __launch_bounds__(256, 1) k_chain_f32(const ChainArgs a) {
       for (int w = 0; w < MW; ++w) mw[w] = 0;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
+        if (!BWD && a.act != 0) {      // tanh / sine (inference only)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) h[t][j] = act_value(h[t][j], a.act, a.act_w0);
+          continue;
+        }
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
           // integer VALU only (see afx_kernels_bf16.hip): max_i32(bits(x),0) = bits(relu(x)); min_u32(.,1) = [x > 0]
@@ -348,6 +376,11 @@ __global__ void __launch_bounds__(256, 1) k_chain_f32(const ChainArgs a) {
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[1], h[u >> 2][4 * (u & 3) + 1], acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[2], h[u >> 2][4 * (u & 3) + 2], acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[3], h[u >> 2][4 * (u & 3) + 3], acc, 0, 0, 0);
+        }
+        if (!BWD && a.act != 0) {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) hn[t][j] = act_value(acc[j], a.act, 1.f);
+          continue;
         }
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -728,6 +761,18 @@ __global__ void k_finish_mse(const float* od_part, int groups, int64_t n_rays, c
   if (r >= n_rays) return;
   float od = 0.f;
   for (int g = 0; g < groups; ++g) od += od_part[r * groups + g];
+  const float T = expf(-od);
+  pixel[r] = T;
+  dod[r] = -T * (2.f * (T - target[r]) * inv_n);
+}
+
+// the same for packed samples: ray r owns the groups [goff[r], goff[r+1]) (none: pixel = 1, the empty product of scatter_mul into ones,
+// nerf/nerf_helpers_acc.py:58)
+__global__ void k_finish_mse_packed(const float* od_part, const int64_t* goff, int64_t n_rays, const float* target, float inv_n, float* pixel, float* dod) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rays) return;
+  float od = 0.f;
+  for (int64_t g = goff[r]; g < goff[r + 1]; ++g) od += od_part[g];
   const float T = expf(-od);
   pixel[r] = T;
   dod[r] = -T * (2.f * (T - target[r]) * inv_n);

@@ -259,6 +259,20 @@ __global__ void k_march_compact(const uint8_t* keep, const int64_t* offsets_in, 
     if (keep[i]) { ri_out[w] = (int32_t)r; ts_out[w] = ts_in[i]; te_out[w] = te_in[i]; ++w; }
 }
 
+// Group-aligned copy of a packed, ray-sorted sample list for the fused packed training step: ray r's samples start at padded index
+// 32 goff[r] (goff = exclusive scan of ceil(count / 32)); the rest of its last 32-sample group is dead padding (ts = te = 0); group_ray[g] = r.
+__global__ void k_pack_groups(const int64_t* offsets, const int64_t* goff, int64_t n_rays, const float* ts_in, const float* te_in,
+                              float* ts_pad, float* te_pad, int32_t* group_ray) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rays) return;
+  const int64_t i0 = offsets[r], cnt = offsets[r + 1] - i0, g0 = goff[r], g1 = goff[r + 1];
+  for (int64_t k = 0; k < (g1 - g0) * 32; ++k) {
+    ts_pad[g0 * 32 + k] = k < cnt ? ts_in[i0 + k] : 0.f;
+    te_pad[g0 * 32 + k] = k < cnt ? te_in[i0 + k] : 0.f;
+  }
+  for (int64_t g = g0; g < g1; ++g) group_ray[g] = (int32_t)r;
+}
+
 // --- device ray sampler (sample_pixel_rays, nerf/nerf_helpers.py:137-150): weighted sampling WITHOUT replacement of k of n
 // rays.  Efraimidis-Spirakis keys: key_i = u_i^(1/w_i) (log form: log(u_i)/w_i), the k largest keys are a weighted sample
 // without replacement; u from Philox (perf mode) or supplied.  The top-k selection is the radix select below.

@@ -60,9 +60,10 @@ class Engine:
     """One CPPN geometry on one GPU."""
 
     def __init__(self, width: int, n_hidden: int, enc: str = "none", n_freq: int = 0,
-                 max_workspace_bytes: int = 24 << 30, variant: str = ""):
+                 max_workspace_bytes: int = 24 << 30, variant: str = "", act: str = "relu", act_w0: float = 1.0):
         self.lib = _lib.load(variant)
-        self.desc = ModelDesc(3, _lib.ENC[enc], int(n_freq), int(width), int(n_hidden))
+        self.act = act
+        self.desc = ModelDesc(3, _lib.ENC[enc], int(n_freq), int(width), int(n_hidden), _lib.ACT[act], float(act_w0))
         h = C.c_void_p()
         self._check(self.lib.afx_create(C.byref(self.desc), C.byref(h)), "afx_create")
         self.h = h
@@ -261,6 +262,26 @@ class Engine:
         del keep
 
 
+    def train_step_packed_mse(self, prepared, origins, dirs, packed: "PackedGroups", target, inv_n: float, grad_flat, prec: str):
+        """afx_train_step_packed_mse: the reference's iteration body on the march's packed samples; returns the pixels [n_rays]."""
+        dev = prepared.device
+        o, d, target = _f32(origins, "origins", dev), _f32(dirs, "dirs", dev), _f32(target, "target", dev)
+        n_rays = packed.n_rays
+        if tuple(o.shape) != (n_rays, 3) or tuple(d.shape) != (n_rays, 3) or target.numel() != n_rays:
+            raise ValueError("train_step_packed_mse: origins/dirs [n_rays,3] and target [n_rays] expected")
+        pixel = torch.empty(n_rays, dtype=torch.float32, device=dev)
+        full = int(self.lib.afx_query(self.h, _lib.Q_BWD_WORKSPACE_FULL, 0, max(packed.n_groups, 1) * 32, _lib.PREC[prec]))
+        full += 4 * (n_rays + packed.n_groups) + 1024
+        if full > self.max_workspace_bytes:
+            raise AfxError(f"train_step_packed_mse: {packed.n_groups * 32} packed samples need a {full >> 20} MiB workspace in one piece "
+                           f"(max_workspace_bytes = {self.max_workspace_bytes >> 20} MiB)")
+        ws = self._workspace(full, dev)
+        self._check(self.lib.afx_train_step_packed_mse(self.h, _lib.PREC[prec], _ptr(prepared), _ptr(o), _ptr(d), n_rays,
+                                                      _ptr(packed.group_offsets), _ptr(packed.group_ray), packed.n_groups,
+                                                      _ptr(packed.ts_pad), _ptr(packed.te_pad), _ptr(target), float(inv_n), _ptr(pixel),
+                                                      _ptr(grad_flat), _ptr(ws), ws.numel(), self._stream(dev)), "afx_train_step_packed_mse")
+        return pixel
+
     def fused_step_available(self, n_samples: int, prec: str) -> bool:
         """afx_train_step_mse takes this ray length at this precision: rays that fit a 256-sample workgroup tile always (one
         kernel per chunk); any other length (300, 128 + 64, ...) as two half-kernels per chunk with the 8-bit-stash kernel, no
@@ -284,6 +305,39 @@ class Engine:
                                                float(inv_n), _ptr(grad_flat), self._stream(dev)), "afx_train_step_mse")
         del keep
         return pixel
+
+
+# ---- packed samples of the occupancy-grid march, group-aligned for the fused packed training step
+class PackedGroups:
+    """A packed, ray-sorted sample list re-laid out for the fused packed training step (afx_pack_groups): every ray starts on a
+    32-sample group (`group_offsets` int64 [R+1] in groups), dead padding behind a ray's last sample, `group_ray` int32 [n_groups]."""
+
+    def __init__(self, n_rays, n_groups, group_offsets, group_ray, ts_pad, te_pad):
+        self.n_rays, self.n_groups = int(n_rays), int(n_groups)
+        self.group_offsets, self.group_ray, self.ts_pad, self.te_pad = group_offsets, group_ray, ts_pad, te_pad
+
+
+def pack_groups(offsets, t_starts, t_ends, n_groups=None, group_offsets=None) -> PackedGroups:
+    """offsets int64 [R+1] (exclusive scan of the per-ray sample counts), t_starts / t_ends [n] -> PackedGroups."""
+    lib = _lib.load()
+    dev = offsets.device
+    if dev.type != "cuda":
+        raise AfxError("pack_groups: the sample list must live on a GPU; there is no CPU fallback")
+    n_rays = offsets.numel() - 1
+    if group_offsets is None:
+        cnt = offsets[1:] - offsets[:-1]
+        group_offsets = torch.zeros(n_rays + 1, dtype=torch.int64, device=dev)
+        torch.cumsum((cnt + 31) // 32, 0, out=group_offsets[1:])
+    if n_groups is None:
+        n_groups = int(group_offsets[-1])
+    ts_pad = torch.empty(n_groups * 32, device=dev)
+    te_pad = torch.empty(n_groups * 32, device=dev)
+    group_ray = torch.empty(n_groups, dtype=torch.int32, device=dev)
+    if n_groups:
+        ts, te = _f32(t_starts.reshape(-1), "t_starts", dev), _f32(t_ends.reshape(-1), "t_ends", dev)
+        _lib.check(lib.afx_pack_groups(_ptr(offsets), _ptr(group_offsets), n_rays, _ptr(ts), _ptr(te), _ptr(ts_pad), _ptr(te_pad),
+                                       _ptr(group_ray), Engine._stream(dev)), "afx_pack_groups")
+    return PackedGroups(n_rays, n_groups, group_offsets, group_ray, ts_pad, te_pad)
 
 
 # ---- stand-alone compositing / sampling kernels (no model) -----------------------------------
@@ -487,7 +541,7 @@ def march(origins, dirs, scene_aabb, near_plane, far_plane, step, grid_bits=None
     return ri, ts, te, pts, offsets
 
 
-def march_visibility(raw, ts, te, offsets, early_stop_eps, alpha_thre, is_alpha=False):
+def march_visibility(raw, ts, te, offsets, early_stop_eps, alpha_thre, is_alpha=False, return_offsets=False):
     """nerfacc render_visibility on the candidates' raw MLP outputs -> compacted (ray_indices, t_starts, t_ends)."""
     lib = _lib.load()
     dev = ts.device
@@ -506,6 +560,8 @@ def march_visibility(raw, ts, te, offsets, early_stop_eps, alpha_thre, is_alpha=
     if n2 > 0:
         _lib.check(lib.afx_march_compact(_ptr(keep), _ptr(offsets), _ptr(off2), n_rays, _ptr(ts), _ptr(te), _ptr(ri2), _ptr(ts2),
                                          _ptr(te2), st), "afx_march_compact")
+    if return_offsets:
+        return ri2, ts2, te2, off2
     return ri2, ts2, te2
 
 

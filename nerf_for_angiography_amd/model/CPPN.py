@@ -149,8 +149,18 @@ class CPPN(nn.Module):
 
     @property
     def fused(self) -> bool:
-        """True when this configuration runs in the fused HIP kernels."""
-        return (self._act_name == "relu" and self.num_late_layers == 0 and not self.use_viewdirs
+        """True when this configuration runs in the fused HIP kernels in BOTH directions (training included)."""
+        return self._act_name == "relu" and self.fused_forward
+
+    @property
+    def fused_forward(self) -> bool:
+        """True when the FORWARD kernels take this configuration: the reference's trained geometry (no skip block, no view
+        directions, one output channel) with any of its three activations.  tanh / sine models are evaluated by the kernels
+        wherever no gradient is wanted (inference, evaluation renders, density grids: the activation is an epilogue of the same
+        chain kernel); with gradients they keep the module's PyTorch-ROCm operators (a tanh / sine backward needs the activation
+        values per element where ReLU needs one bit)."""
+        return ((self._act_name == "relu" or (self._act_name in ("tanh", "sine") and self.use_pos_enc == "none"))
+                and self.num_late_layers == 0 and not self.use_viewdirs
                 and self.num_output_channels == 1 and self.num_input_channels == 3 and self.use_bias
                 and self.num_filters in (64, 128, 256) and 1 <= self.num_early_layers <= 16
                 and self.use_pos_enc in ("none", "barf", "fourier")
@@ -172,7 +182,7 @@ class CPPN(nn.Module):
 
     def _flatten(self):
         """Make every Linear's weight/bias a view into one flat fp32 buffer (the C-ABI's parameter layout)."""
-        if not self.fused:
+        if not self.fused_forward:
             return
         lins = self._linears()
         layout, total = self._layout()
@@ -202,7 +212,8 @@ class CPPN(nn.Module):
         if self._engine is None:
             from ..engine import Engine
             self._engine = Engine(self.num_filters, self.num_early_layers, self.use_pos_enc,
-                                  self.pos_enc_basis if self.use_pos_enc != "none" else 0)
+                                  self.pos_enc_basis if self.use_pos_enc != "none" else 0, act=self._act_name,
+                                  act_w0=float(self.model_definition.get("sine_weights", 1.0)) if self._act_name == "sine" else 1.0)
             if self._engine.param_count != self._flat.numel():
                 raise RuntimeError("flat parameter layout disagrees with afx_param_layout")
         return self._engine
@@ -296,10 +307,15 @@ class CPPN(nn.Module):
             self.activation_dictionary = {}
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        if self.fused and x.is_cuda and x.shape[-1] == self.num_input_channels:
-            pts = x.reshape(-1, 3).float().contiguous()
-            out = _MlpFn.apply(self, pts, *self._fn_params())
-            return out.reshape(*x.shape[:-1], 1)
+        if x.is_cuda and x.shape[-1] == self.num_input_channels:
+            if self.fused:
+                pts = x.reshape(-1, 3).float().contiguous()
+                out = _MlpFn.apply(self, pts, *self._fn_params())
+                return out.reshape(*x.shape[:-1], 1)
+            if self.fused_forward and not (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))):
+                # tanh / sine: the forward kernels, where no gradient is being recorded
+                pts = x.reshape(-1, 3).float().contiguous()
+                return self.engine.infer(self._prepared(), pts, self.precision).reshape(*x.shape[:-1], 1)
         return self._forward_ops(x)
 
     def _forward_ops(self, x: torch.Tensor) -> torch.Tensor:

@@ -7,7 +7,7 @@ from .. import engine as _engine
 
 
 def acc_ray_marching(radiance_field, grid, scene_aabb, ray_origins, ray_directions, depth_samples_per_ray,
-                     near_thresh, far_thresh, early_stop_eps=1e-2, alpha_thre=1e-3):
+                     near_thresh, far_thresh, early_stop_eps=1e-2, alpha_thre=1e-3, return_packed=False):
     """nerf/nerf_helpers_acc.py:10-31 -> (ray_indices[n], t_starts[n,1], t_ends[n,1]), packed and ray-sorted.
 
     grid=None and scene_aabb=None: every ray is marched with the fixed step (far-near)/depth_samples_per_ray from
@@ -30,7 +30,7 @@ def acc_ray_marching(radiance_field, grid, scene_aabb, ray_origins, ray_directio
     from .occupancy import ray_marching
     return ray_marching(ray_origins, ray_directions, scene_aabb=scene_aabb, grid=grid, raw_fn=radiance_field,
                         near_plane=near_thresh, far_plane=far_thresh, early_stop_eps=early_stop_eps,
-                        alpha_thre=alpha_thre, render_step_size=render_step_size)
+                        alpha_thre=alpha_thre, render_step_size=render_step_size, return_packed=return_packed)
 
 
 def get_ray_entropy(sigmas, rgb_map, threshold=0.4):

@@ -20,7 +20,11 @@ the CPU for the tests.  Semantics kept:
 
 The grid lives on the GPU (there is no CPU fallback).  Randomness: which cells are refreshed is a torch draw (an index
 list is data); the jitter inside a cell is drawn in the kernel from the counter-based Philox stream (seed, step) unless
-the caller passes `jitter` (parity tests)."""
+the caller passes `jitter` (parity tests).
+
+`ray_marching(..., return_packed=True)` additionally returns the kept samples group-aligned (engine.PackedGroups) for the fused
+packed training step (`render.train_step_packed_mse`: the reference's positions -> get_predictions -> acc_render_volume_density -> mse ->
+backward in one pass)."""
 from __future__ import annotations
 
 import torch
@@ -152,7 +156,7 @@ class OccupancyGrid(torch.nn.Module):
 
 @torch.no_grad()
 def ray_marching(rays_o, rays_d, scene_aabb=None, grid=None, alpha_fn=None, near_plane=None, far_plane=None,
-                 early_stop_eps=1e-4, alpha_thre=0.0, render_step_size=1e-3, raw_fn=None):
+                 early_stop_eps=1e-4, alpha_thre=0.0, render_step_size=1e-3, raw_fn=None, return_packed=False):
     """nerfacc.ray_marching on the HIP kernels.  `alpha_fn(t_starts[n,1], t_ends[n,1], ray_indices[n]) -> alpha[n,1]` is the
     upstream callback; `raw_fn(points[n,3]) -> raw[n,1]` is the short-cut the reference's alpha_fn reduces to (sigmoid
     density at the interval mid-point): the mid-points come out of the march kernel and alpha is formed in the visibility
@@ -165,10 +169,14 @@ def ray_marching(rays_o, rays_d, scene_aabb=None, grid=None, alpha_fn=None, near
                                              grid_aabb=None if grid is None else grid._aabb_host,
                                              grid_res=None if grid is None else grid._res_host, want_points=raw_fn is not None)
     if (alpha_fn is None and raw_fn is None) or ri.numel() == 0:
+        if return_packed:
+            return ri, ts[:, None], te[:, None], _engine.pack_groups(offsets, ts, te)
         return ri, ts[:, None], te[:, None]
     if raw_fn is not None:
         vals, is_alpha = raw_fn(pts).reshape(-1).float(), False
     else:
         vals, is_alpha = alpha_fn(ts[:, None], te[:, None], ri.long()).reshape(-1).float(), True
-    ri2, ts2, te2 = _engine.march_visibility(vals, ts, te, offsets, early_stop_eps, alpha_thre, is_alpha=is_alpha)
+    ri2, ts2, te2, off2 = _engine.march_visibility(vals, ts, te, offsets, early_stop_eps, alpha_thre, is_alpha=is_alpha, return_offsets=True)
+    if return_packed:      # + the group-aligned copy render.train_step_packed_mse takes
+        return ri2, ts2[:, None], te2[:, None], _engine.pack_groups(off2, ts2, te2)
     return ri2, ts2[:, None], te2[:, None]

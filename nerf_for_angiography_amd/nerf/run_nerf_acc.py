@@ -6,10 +6,12 @@ weights), BARF schedule, learning-rate decay, evaluation cadence, best-PSNR / ve
 early stopping.  Differences: the dataset comes from `load_data` (which the reference calls but never defines) or
 is synthesised in memory; TensorBoard/pyvista outputs are replaced by a JSONL log.
 
-Two iteration bodies (--march): `dense` (default) is ONE fused launch per ray chunk (`train_step_mse`: ray -> samples ->
+Three iteration bodies (--march): `dense` (default) is ONE fused launch per ray chunk (`train_step_mse`: ray -> samples ->
 MLP -> Beer-Lambert -> MSE -> backward; render + autograd with --precision f32); `grid` is the reference's own body,
-run_nerf_acc.py:284-306, call for call - acc_update_n_step, acc_ray_marching with the occupancy grid (HIP march /
-visibility kernels, nerf/occupancy.py), positions, get_predictions, acc_render_volume_density, mse_loss, backward.
+run_nerf_acc.py:284-306 - acc_update_n_step for both grids, acc_ray_marching with the occupancy grid (HIP march / visibility
+kernels, nerf/occupancy.py), then positions / get_predictions / acc_render_volume_density / mse_loss / backward as ONE fused pass
+over the march's packed samples (`train_step_packed_mse`; f16s8, no encoding); `grid_ops` is the same body call for call through
+the mirrored functions (also what `grid` does at the other precisions / with an encoding).
 The training rays live on the GPU: one table (origins, directions, pixel, weight) built once, and every iteration's
 batch is drawn there (weighted sampling without replacement, `engine.sample_rays`); --host_sampler restores the
 reference's per-iteration pandas draw (`sample_pixel_rays`).
@@ -31,7 +33,7 @@ from ..engine import RenderSpec
 from ..model.CPPN import CPPN
 from ..phantomdata import dataset as ds
 from .. import engine as _engine
-from ..render import render_rays, train_step_mse
+from ..render import render_rays, train_step_mse, train_step_packed_mse
 from .nerf_helpers import sample_pixel_rays, get_predictions
 from .nerf_helpers_acc import acc_ray_marching, acc_render_volume_density, acc_update_n_step
 from .occupancy import OccupancyGrid, ContractionType
@@ -60,8 +62,10 @@ def build_parser():
     p.add_argument('--precision', default='f16s8', choices=['f32', 'bf16x3', 'bf16', 'f16', 'f16s8'],
                    help='arithmetic of the training step (include/afx.h); f16s8 = f16 with the backward stash kept as bf8')
     p.add_argument('--eval_precision', default='f16', choices=['f32', 'bf16x3', 'bf16', 'f16'])
-    p.add_argument('--march', default='dense', choices=['dense', 'grid'],
-                   help='dense: fused fixed-step march (one launch per ray chunk); grid: the reference loop with the occupancy grid')
+    p.add_argument('--march', default='dense', choices=['dense', 'grid', 'grid_ops'],
+                   help='dense: fused fixed-step march (one launch per ray chunk); grid: the reference loop with the occupancy grid, its body behind '
+                        'the march (positions, get_predictions, acc_render_volume_density, mse, backward) as ONE fused packed step at the f16s8 '
+                        'precision; grid_ops: the same loop call for call through the mirrored functions')
     p.add_argument('--host_sampler', action='store_true', help="draw each batch with pandas on the host (the reference's sample_pixel_rays)")
     p.add_argument('--log_dir', default='runs/afx')
     p.add_argument('--seed', type=int, default=0)
@@ -149,10 +153,11 @@ def main(argv=None):
     early_stop_eps, alpha_thre, vessel_alpha_thre = 1e-2, 1e-4, 5e-2
     scene_aabb = torch.tensor([-outside, -outside, -outside, outside, outside, outside], dtype=torch.float32, device=device)
     acc_grid = OccupancyGrid(roi_aabb=scene_aabb, resolution=128, contraction_type=ContractionType.AABB, seed=args.seed).to(device) \
-        if args.march == 'grid' else None
+        if args.march != 'dense' else None
     # the reference's second grid (:198,286): same updates at the vessel threshold; it only feeds the exported occupancy volumes (:362-367)
     vessel_acc_grid = OccupancyGrid(roi_aabb=scene_aabb, resolution=128, contraction_type=ContractionType.AABB, seed=args.seed + 1).to(device) \
-        if args.march == 'grid' else None
+        if args.march != 'dense' else None
+    packed_step = args.march == 'grid' and args.precision == 'f16s8' and args.pos_enc == 'none'      # else the operator sequence
     batch_size = 131072
 
     os.makedirs(args.log_dir, exist_ok=True)
@@ -173,17 +178,22 @@ def main(argv=None):
             batch_origins, batch_directions, batch_pix_vals, _ = _engine.sample_rays(tab_o, tab_d, tab_pix, tab_w, img_sample_size,
                                                                                      seed=args.seed, stream_id=n_iter)
         coarse_optimizer.zero_grad()
-        if args.march == 'grid':
+        if args.march != 'dense':
             # the reference's iteration body, run_nerf_acc.py:284-306
             with torch.no_grad():
                 acc_grid.train()
                 vessel_acc_grid.train()
                 acc_grid = acc_update_n_step(acc_grid, coarse_model, n_iter, occ_thre=alpha_thre)
                 vessel_acc_grid = acc_update_n_step(vessel_acc_grid, coarse_model, n_iter, occ_thre=vessel_alpha_thre)
-                ray_indices, t_starts, t_ends = acc_ray_marching(coarse_model, acc_grid, scene_aabb, batch_origins, batch_directions,
-                                                                 depth_samples_per_ray_coarse, near_thresh, far_thresh,
-                                                                 early_stop_eps, alpha_thre)
-            if len(ray_indices) > 0:
+                marched = acc_ray_marching(coarse_model, acc_grid, scene_aabb, batch_origins, batch_directions,
+                                           depth_samples_per_ray_coarse, near_thresh, far_thresh, early_stop_eps, alpha_thre,
+                                           return_packed=packed_step)
+                ray_indices, t_starts, t_ends = marched[:3]
+            if len(ray_indices) > 0 and packed_step:
+                # :289-306 in one fused pass over the packed samples (forward half, per-ray product, backward half; MLP evaluated once)
+                loss_coarse, pred = train_step_packed_mse(coarse_model, batch_origins, batch_directions, marched[3], batch_pix_vals)
+                n_marched += int(len(ray_indices))
+            elif len(ray_indices) > 0:
                 positions = batch_origins[ray_indices.long()] + batch_directions[ray_indices.long()] * (t_starts + t_ends) / 2.0
                 predictions = get_predictions(coarse_model, positions, batch_size)
                 pred, _ = acc_render_volume_density(predictions, ray_indices, t_starts, t_ends, img_sample_size,
@@ -200,7 +210,7 @@ def main(argv=None):
             loss_coarse, pred = train_step_mse(coarse_model, RenderSpec(
                 n_rays=img_sample_size, n_samples=depth_samples_per_ray_coarse, origins=batch_origins,
                 dirs=batch_directions, mode='acc', t_near=near_thresh, t_far=far_thresh), batch_pix_vals)
-        if args.march != 'grid' or len(ray_indices) > 0:      # (the reference steps only when the march kept samples, :293)
+        if args.march == 'dense' or len(ray_indices) > 0:      # (the reference steps only when the march kept samples, :293)
             coarse_optimizer.step()
         new_lr_coarse = coarse_lr * (decay_rate ** (n_iter / decay_steps))
         for param_group in coarse_optimizer.param_groups:
@@ -210,7 +220,7 @@ def main(argv=None):
             coarse_model.eval()
             keep, coarse_model.precision = coarse_model.precision, args.eval_precision
             with torch.no_grad():
-                if args.march == 'grid':          # run_nerf_acc.py:338-349
+                if args.march != 'dense':          # run_nerf_acc.py:338-349
                     ri_t, ts_t, te_t = acc_ray_marching(coarse_model, acc_grid, scene_aabb, test_origins, test_directions,
                                                         depth_samples_per_ray_coarse, near_thresh, far_thresh, early_stop_eps, alpha_thre)
                     pos_t = test_origins[ri_t.long()] + test_directions[ri_t.long()] * (ts_t + te_t) / 2.0
@@ -229,7 +239,7 @@ def main(argv=None):
                        test_psnr=psnr, test_vessel_psnr=vessel_psnr, lr=new_lr_coarse,
                        barf_alpha=float(getattr(coarse_model, 'barf_alpha', 0.0)), sec=round(time.time() - t_last, 3),
                        it_per_s=round(display_every / max(time.time() - t_last, 1e-9), 1) if n_iter else 0.0,
-                       marched_samples_per_iter=(n_marched // max(display_every, 1)) if args.march == 'grid' else
+                       marched_samples_per_iter=(n_marched // max(display_every, 1)) if args.march != 'dense' else
                        img_sample_size * depth_samples_per_ray_coarse)
             n_marched = 0
             t_last = time.time()

@@ -55,8 +55,11 @@ class _RenderFn(torch.autograd.Function):
 
 def _check_model(model):
     if not getattr(model, "fused", False):
-        raise NotImplementedError("render_rays: this CPPN configuration is outside the fused kernels "
-                                  "(ReLU, no skip block, no view directions, one output channel)")
+        if getattr(model, "fused_forward", False) and not torch.is_grad_enabled():
+            pass      # tanh / sine models: forward kernels only (evaluation renders, density grids under torch.no_grad())
+        else:
+            raise NotImplementedError("render_rays: this CPPN configuration is outside the fused kernels (ReLU - or tanh / sine under "
+                                      "torch.no_grad() -, no skip block, no view directions, one output channel)")
     if model.flat_params is None or not model.flat_params.is_cuda:
         raise AfxError("render_rays: the model must live on a GPU; there is no CPU fallback")
 
@@ -174,6 +177,31 @@ def train_step_mse(model, spec: RenderSpec, target: torch.Tensor, n_global: Opti
     return loss, pixel
 
 
+def train_step_packed_mse(model, ray_origins, ray_directions, packed, target: torch.Tensor, n_global: Optional[int] = None):
+    """The reference's iteration body behind the occupancy-grid march - positions, get_predictions, acc_render_volume_density,
+    mse_loss, backward (nerf/run_nerf_acc.py:289-306) - as ONE fused pass over the march's packed samples (engine.PackedGroups, from
+    `occupancy.ray_marching(..., return_packed=True)` or `engine.pack_groups`): forward half, per-ray transmittance product, backward
+    half, weight gradients; the MLP is evaluated once (the operator sequence evaluates it in the forward and again inside backward).
+    f16s8 precision, no input encoding.  Gradients are ACCUMULATED into `.grad` as loss.backward() would.  Returns (loss, pixels[n_rays]);
+    a ray without samples renders 1 (the empty product)."""
+    _check_model(model)
+    if model.precision != "f16s8" or model.engine.enc != "none":
+        raise NotImplementedError("train_step_packed_mse: precision 'f16s8' without an input encoding (other configurations: the operator sequence "
+                                  "get_predictions -> acc_render_volume_density -> mse_loss -> backward)")
+    n = _global_rays(packed.n_rays, n_global, model.flat_params.device)
+    flat_grad = torch.zeros(model.engine.param_count, dtype=torch.float32, device=model.flat_params.device)
+    pixel = model.engine.train_step_packed_mse(model._prepared(), ray_origins, ray_directions, packed, target, 1.0 / n, flat_grad, model.precision)
+    if _grad_hook is not None:
+        _grad_hook(flat_grad)
+    for p, g in zip(model._fn_params(), model._fn_grads(flat_grad, None)):
+        if p.grad is None:
+            p.grad = g
+        else:
+            p.grad.add_(g)
+    loss = ((pixel - target) ** 2).sum() / n
+    return loss, pixel
+
+
 def hierarchical_train_step_mse(model, ray_origins, ray_directions, depth_values, depth_samples_per_ray_fine: int,
                                 target: torch.Tensor, u: Optional[torch.Tensor] = None, n_global: Optional[int] = None,
                                 fine_model=None):
@@ -234,7 +262,8 @@ def density_grid(model, outside: float, n: int, precision: Optional[str] = None)
     otherwise GRID_PRECISION (split bf16) whatever the model trains at: the reconstructed grid is held to 1e-4 relative L2 against the reference's fp32 path, which the training
     precisions miss (f16: ~1e-3 on sigmoid(raw), tests/test_gpu_round3.py) - pixels average that error over a ray, a
     grid cell does not.  201^3 points take ~25 ms in split bf16."""
-    _check_model(model)
+    with torch.no_grad():
+        _check_model(model)
     dev = model.flat_params.device
     t = torch.linspace(-outside, outside, n + 1, dtype=torch.float64, device=dev).float()
     gy, gx, gz = torch.meshgrid(t, t, t, indexing="ij")      # [i,j,k] -> (x=t[j], y=t[i], z=t[k])

@@ -477,3 +477,139 @@ def test_hierarchical_train_step_fused_pieces_vs_oracle_and_autograd_path():
     assert bool(agree)
     assert rel_l2(pix.cpu().numpy(), rgb.detach().cpu().numpy()) < 2e-3
     assert float((g_fused - g_ops).norm() / g_ops.norm()) < 2 * TOL["f16s8"]["grad"]
+
+
+# ------------------------------------------------------------------------------------------------ R7: tanh / sine in the forward kernels
+def _act_model(g, act, layers=4, width=64, precision="f32", **extra):
+    from nerf_for_angiography_amd.model.CPPN import CPPN
+    md = dict(num_early_layers=layers, num_late_layers=0, num_filters=width, num_input_channels=3, num_output_channels=1,
+              num_input_channels_views=0, use_bias=True, pos_enc="none", pos_enc_basis=5, act_func=act, fourier_sigma=5, num_img=1,
+              device=torch.device(DEV), precision=precision, **extra)
+    m = CPPN(md).to(DEV)
+    return load_sd(m, g) if g is not None else m
+
+
+@pytest.mark.parametrize("act,extra", [("tanh", {}), ("sine", {"sine_weights": 15})])
+def test_tanh_sine_forward_kernels_vs_reference_fixture(golden, act, extra):
+    """CPPN act_func 'tanh' / 'sine' (model/CPPN.py:53-60,278-300; G4 captured from the reference's CPPN with sine w0 = 15): the activation is an
+    epilogue of the forward chain kernels.  Under torch.no_grad() the module's forward IS the kernel (exact-fp32 and split-bf16 at the
+    1e-5 / 5e-5 bars of the ReLU fixtures; f16 bounded), with gradients recorded it is the module's PyTorch operators, and both agree."""
+    g = golden(f"g4_cppn_none_{act}_4x64")
+    x = T(g["x"])
+    m = _act_model(g, act, **extra)
+    assert m.fused_forward and not m.fused
+    with torch.no_grad():
+        y32 = m(x)
+        assert rel_l2(y32.cpu().numpy(), g["y"]) < (1e-5 if act == "tanh" else 3e-5)      # sin(15 z): one ulp of z is 15 ulps of the argument
+        m.precision = "bf16x3"
+        assert rel_l2(m(x).cpu().numpy(), g["y"]) < 5e-5
+        m.precision = "f16"
+        assert rel_l2(m(x).cpu().numpy(), g["y"]) < (3e-3 if act == "tanh" else 3e-2)      # sin(15 z): f16 operands in front of a steep argument
+        m.precision = "f32"
+    y_ops = m(x)                                  # gradients recorded: operator route
+    assert y_ops.requires_grad and rel_l2(y_ops.detach().cpu().numpy(), g["y"]) < 3e-5
+    y_ops.sum().backward()
+    assert all(p.grad is not None for p in m._hip_params())
+
+
+@pytest.mark.parametrize("act,extra", [("tanh", {}), ("sine", {"sine_weights": 2.0})])
+def test_tanh_sine_render_and_density_grid_vs_oracle(act, extra):
+    """Evaluation renders (in-kernel ray generation, acc convention) and the density grid of tanh / sine models under torch.no_grad(), 8 hidden
+    layers of width 128, against the CPU oracle; asking for gradients through the fused renderer is refused."""
+    from oracle import angio_oracle as orc
+    from nerf_for_angiography_amd.render import render_rays, density_grid
+    torch.manual_seed(31)
+    m = _act_model(None, act, layers=8, width=128, **extra)
+    with torch.no_grad():
+        m.output_linear[0].bias.fill_(-4.0)
+    o, d, _ = _ref_iteration_problem(300, seed=4)
+    cfg = dict(num_early_layers=8, num_filters=128, act_func=act, **extra)
+    params = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        want = orc.render_rays(o, d, cfg, params, near=1400.0, far=1600.0, n_samples=96, convention="acc")
+        got = render_rays(m, o.to(DEV), d.to(DEV), 96, 1400.0, 1600.0, mode="acc").rgb_map
+        assert rel_l2(got.cpu().numpy(), want.numpy()) < 1e-4
+        grid = density_grid(m, 100.0, 12)
+        pts = orc.density_grid_points(100.0, 12)
+        sig = torch.sigmoid(orc.cppn_forward(pts, cfg, params)).reshape(13, 13, 13)
+        assert rel_l2(grid.cpu().numpy(), sig.numpy()) < 1e-4
+    with pytest.raises(NotImplementedError):
+        render_rays(m, o.to(DEV), d.to(DEV), 96, 1400.0, 1600.0, mode="acc")
+
+
+# ------------------------------------------------------------------------------------------------ fused packed step (grid-march iteration)
+def _packed_problem(n_rays, seed, empty_every=0):
+    """Rays, a ball-shaped occupancy grid, the march's packed samples (no visibility pruning so that the list is a pure function of the grid)."""
+    from nerf_for_angiography_amd.nerf.occupancy import OccupancyGrid, ray_marching
+    o, d, tgt = _ref_iteration_problem(n_rays, seed=seed)
+    aabb = torch.tensor([-100.0, -100, -100, 100, 100, 100])
+    res = 32
+    c = (torch.stack(torch.meshgrid(*[torch.arange(res)] * 3, indexing="ij"), -1).float() + 0.5) / res * 200 - 100
+    mask = c.norm(dim=-1) < 60
+    grid = OccupancyGrid(roi_aabb=aabb, resolution=res).to(DEV)
+    grid._binary = mask.to(DEV)
+    if empty_every:      # some rays that miss everything: no samples, pixel = 1
+        d = d.clone()
+        d[::empty_every] = torch.tensor([0.9, 0.3, -0.3])
+    ri, ts, te, packed = ray_marching(o.to(DEV), d.to(DEV), scene_aabb=aabb, grid=grid, near_plane=1400.0, far_plane=1600.0,
+                                      render_step_size=200.0 / 300, return_packed=True)
+    return o.to(DEV), d.to(DEV), tgt.to(DEV), ri, ts, te, packed
+
+
+@pytest.mark.parametrize("layers,width,n_rays", [(4, 128, 5625), (8, 256, 2000), (2, 64, 3)])
+def test_fused_packed_step_vs_operator_sequence_and_fp32(layers, width, n_rays):
+    """render.train_step_packed_mse - the reference's positions -> get_predictions -> acc_render_volume_density -> mse_loss -> backward
+    (nerf/run_nerf_acc.py:289-306) as one fused pass over the grid march's packed samples - against that operator sequence through the mirrored
+    functions at the exact-fp32 kernels (gradients) and at f16 (pixels bit-for-bit: same forward arithmetic); rays without samples render 1."""
+    from nerf_for_angiography_amd.render import train_step_packed_mse
+    from nerf_for_angiography_amd.nerf.nerf_helpers import get_predictions
+    from nerf_for_angiography_amd.nerf.nerf_helpers_acc import acc_render_volume_density
+    o, d, tgt, ri, ts, te, packed = _packed_problem(n_rays, seed=layers + width, empty_every=7)
+    assert packed.n_groups * 32 >= ri.numel() > 0 and int(packed.group_offsets[-1]) == packed.n_groups
+    cnt = torch.bincount(ri.long(), minlength=n_rays)
+    assert int((cnt == 0).sum()) > 0 or n_rays < 7
+    torch.manual_seed(3)
+    m = make_model(layers, width, precision="f32")
+    with torch.no_grad():
+        m.output_linear[0].weight.mul_(4.0)
+        m.output_linear[0].bias.fill_(-5.0)
+
+    def ops_step(prec):
+        m.precision = prec
+        m.zero_grad(set_to_none=True)
+        pos = o[ri.long()] + d[ri.long()] * (ts + te) / 2.0
+        pred, _ = acc_render_volume_density(get_predictions(m, pos, 131072), ri, ts, te, n_rays, 300)
+        loss = torch.nn.functional.mse_loss(pred, tgt)
+        loss.backward()
+        return pred.detach(), torch.cat([p.grad.reshape(-1) for p in m._hip_params()]).double(), float(loss)
+
+    pix32, g32, loss32 = ops_step("f32")
+    pix16, _, _ = ops_step("f16")
+    m.precision = "f16s8"
+    m.zero_grad(set_to_none=True)
+    loss, pix = train_step_packed_mse(m, o, d, packed, tgt)
+    g8 = torch.cat([p.grad.reshape(-1) for p in m._hip_params()]).double()
+    assert bool((pix[cnt == 0] == 1.0).all())
+    few = ri.numel() < 100000
+    assert rel_l2(pix.cpu().numpy(), pix16.cpu().numpy()) < 1e-6          # same f16 forward; the per-ray product is summed in a different order
+    assert rel_l2(pix.cpu().numpy(), pix32.cpu().numpy()) < (2e-2 if few else 2e-3)
+    assert abs(float(loss) - loss32) < 2e-3 * loss32 + 1e-7
+    e = float((g8 - g32).norm() / g32.norm())
+    assert e < (0.25 if few else TOL["f16s8"]["grad"]), e
+
+
+def test_training_driver_grid_march_fused_packed_step(tmp_path):
+    """--march grid: the reference's loop with the body behind the march as one fused packed step; --march grid_ops: call for call.  Both train
+    (same seeds, same device sampler) and land on similar losses."""
+    from nerf_for_angiography_amd.nerf.run_nerf_acc import main
+    res = {}
+    for march in ("grid", "grid_ops"):
+        out = main(["--synthetic", "--img_size", "24", "--number_angles", "1", "--limited_size", "90", "--n_iters", "96", "--display_every", "48",
+                    "--sample_size", "20", "--depth_samples", "96", "--num_layers", "4", "--num_hidden_units", "64", "--march", march,
+                    "--log_dir", str(tmp_path / march)])
+        h = out["history"]
+        assert h[-1]["train_loss"] < h[0]["train_loss"] and all(np.isfinite(r["test_psnr"]) for r in h)
+        assert h[-1]["marched_samples_per_iter"] > 0
+        res[march] = h[-1]["train_loss"]
+        assert os.path.exists(str(tmp_path / march / "vessel_acc_grid_binary.npy"))
+    assert abs(res["grid"] - res["grid_ops"]) < 0.3 * res["grid_ops"]

@@ -81,9 +81,13 @@ def test_context_queries_and_validation_without_gpu():
     lib.afx_destroy(h)
     # bad descriptors are refused with a message
     for bad in (_lib.ModelDesc(2, 0, 0, 256, 8), _lib.ModelDesc(3, 0, 0, 100, 8), _lib.ModelDesc(3, 1, 0, 64, 4),
-                _lib.ModelDesc(3, 0, 0, 64, 0)):
+                _lib.ModelDesc(3, 0, 0, 64, 0), _lib.ModelDesc(3, 0, 0, 64, 4, 3, 1.0),          # unknown activation
+                _lib.ModelDesc(3, 1, 5, 64, 4, _lib.ACT["tanh"], 1.0)):                            # tanh / sine: without an input encoding only
         assert lib.afx_create(C.byref(bad), C.byref(h)) == -1
         assert lib.afx_last_error()
+    d = _lib.ModelDesc(3, 0, 0, 128, 4, _lib.ACT["sine"], 15.0)       # forward-only activation: accepted; its workspace queries answer as usual
+    assert lib.afx_create(C.byref(d), C.byref(h)) == 0 and lib.afx_query(h, _lib.Q_PARAM_COUNT, 0, 0, 0) == 128 * 3 + 128 + 4 * (128 * 128 + 128) + 129
+    lib.afx_destroy(h)
     d = _lib.ModelDesc(3, 1, 5, 64, 4)
     assert lib.afx_create(C.byref(d), C.byref(h)) == 0
     assert lib.afx_query(h, _lib.Q_K0, 0, 0, 0) == 33
