@@ -718,6 +718,7 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
     w.partial = partial; w.partial2 = partial2; w.partial_s = partial_s; w.debug = a.debug; w.small_groups = sg ? 1 : 0;
     w.gmax = a.gmax; w.stash_esz = (int)esz; w.gexp = a.gexp; w.enc16 = enc16 ? 1 : 0; w.coef_cols = a.coef_cols;
     w.dod = split ? a.dod : nullptr; w.gpr = a.s_pad / GROUP; w.group0 = t0 * (TILE / GROUP); w.group_ray = goff ? a.group_ray : nullptr;
+    w.n_groups_valid = goff ? a.n_total / GROUP : n_rays * (int64_t)(a.s_pad / GROUP);
     ReduceArgs rd;
     rd.partial = partial; rd.partial2 = partial2; rd.n_hidden = N; rd.k0 = c->k0; rd.k0pad = k0ld; rd.n_splits = splits;
     rd.grad = grad_flat; rd.hidden_only = b16 ? 1 : 0; rd.partial_s = partial_s;

@@ -118,6 +118,7 @@ struct WgradArgs {
   const int32_t* group_ray; // packed samples: ray of each group (then dod[group_ray[g]]), else null (dod[(group0 + g) / gpr])
   int32_t gpr;              // 32-sample groups per ray (s_pad / 32)
   int64_t group0;           // global index of the chunk's first group
+  int64_t n_groups_valid;   // groups that belong to a ray (the chunk's last tile may be padded with dead groups beyond them)
 };
 
 struct ReduceArgs {

@@ -1466,7 +1466,12 @@ __global__ void __launch_bounds__(F) k_small_from_groups(const WgradArgs a) {
   for (int64_t g = g0; g < g1; ++g) {
     const float* rec = base + g * RS;
     // (split phases: SW and sum g were formed with g' = g / dod[ray]; a group never straddles rays)
-    const float ds = a.dod ? a.dod[a.group_ray ? (int64_t)a.group_ray[a.group0 + g] : (a.group0 + g) / a.gpr] : 1.f;
+    // (the groups that pad the last tile belong to no ray: their sums are zero, and neither group_ray nor dod has an entry for them)
+    float ds = 1.f;
+    if (a.dod) {
+      const int64_t gg = a.group0 + g;
+      ds = gg < a.n_groups_valid ? a.dod[a.group_ray ? (int64_t)a.group_ray[gg] : gg / a.gpr] : 0.f;
+    }
     const float sw = rec[p] * ds;
     if (a.enc16) {          // encoded inputs: only the output layer's sums are in the records (first layer: k_wgrad_s8)
       aw += sw;

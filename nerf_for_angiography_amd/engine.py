@@ -554,12 +554,20 @@ def march_visibility(raw, ts, te, offsets, early_stop_eps, alpha_thre, is_alpha=
                                         float(alpha_thre), _ptr(keep), _ptr(counts), st), "afx_march_visibility")
     off2 = torch.zeros(n_rays + 1, dtype=torch.int64, device=dev)
     torch.cumsum(counts, 0, out=off2[1:])
-    n2 = int(off2[-1])
+    goff = None
+    if return_offsets == "groups":      # + the group offsets of the group-aligned copy, fetched with the same host sync
+        goff = torch.zeros(n_rays + 1, dtype=torch.int64, device=dev)
+        torch.cumsum((counts + 31) // 32, 0, out=goff[1:])
+        n2, n_groups = torch.stack([off2[-1], goff[-1]]).tolist()
+    else:
+        n2 = int(off2[-1])
     ri2 = torch.empty(n2, dtype=torch.int32, device=dev)
     ts2, te2 = torch.empty(n2, device=dev), torch.empty(n2, device=dev)
     if n2 > 0:
         _lib.check(lib.afx_march_compact(_ptr(keep), _ptr(offsets), _ptr(off2), n_rays, _ptr(ts), _ptr(te), _ptr(ri2), _ptr(ts2),
                                          _ptr(te2), st), "afx_march_compact")
+    if return_offsets == "groups":
+        return ri2, ts2, te2, off2, goff, int(n_groups)
     if return_offsets:
         return ri2, ts2, te2, off2
     return ri2, ts2, te2

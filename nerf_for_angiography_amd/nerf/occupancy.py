@@ -176,7 +176,9 @@ def ray_marching(rays_o, rays_d, scene_aabb=None, grid=None, alpha_fn=None, near
         vals, is_alpha = raw_fn(pts).reshape(-1).float(), False
     else:
         vals, is_alpha = alpha_fn(ts[:, None], te[:, None], ri.long()).reshape(-1).float(), True
-    ri2, ts2, te2, off2 = _engine.march_visibility(vals, ts, te, offsets, early_stop_eps, alpha_thre, is_alpha=is_alpha, return_offsets=True)
-    if return_packed:      # + the group-aligned copy render.train_step_packed_mse takes
-        return ri2, ts2[:, None], te2[:, None], _engine.pack_groups(off2, ts2, te2)
+    if return_packed:      # + the group-aligned copy render.train_step_packed_mse takes (its size comes with the same host sync)
+        ri2, ts2, te2, off2, goff, ng = _engine.march_visibility(vals, ts, te, offsets, early_stop_eps, alpha_thre, is_alpha=is_alpha,
+                                                                 return_offsets="groups")
+        return ri2, ts2[:, None], te2[:, None], _engine.pack_groups(off2, ts2, te2, n_groups=ng, group_offsets=goff)
+    ri2, ts2, te2 = _engine.march_visibility(vals, ts, te, offsets, early_stop_eps, alpha_thre, is_alpha=is_alpha)
     return ri2, ts2[:, None], te2[:, None]

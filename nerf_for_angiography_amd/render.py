@@ -251,6 +251,8 @@ GRID_PRECISION = "bf16x3"      # default arithmetic of density_grid: split bf16 
 
 def grid_precision(model) -> str:
     """Arithmetic of a density-grid evaluation: the model's own precision when it is a strict one (f32, bf16x3), else split bf16."""
+    if getattr(model, "_act_name", "relu") == "sine":
+        return "f32"      # sin(w0 z) amplifies the first layer's operand rounding by w0: split bf16 measures 1e-3 at w0 = 15
     return model.precision if model.precision in ("f32", "bf16x3") else GRID_PRECISION
 
 

@@ -502,7 +502,9 @@ def test_tanh_sine_forward_kernels_vs_reference_fixture(golden, act, extra):
         y32 = m(x)
         assert rel_l2(y32.cpu().numpy(), g["y"]) < (1e-5 if act == "tanh" else 3e-5)      # sin(15 z): one ulp of z is 15 ulps of the argument
         m.precision = "bf16x3"
-        assert rel_l2(m(x).cpu().numpy(), g["y"]) < 5e-5
+        # (split bf16 carries ~2^-17 per product: 4e-4 absolute on a first-layer pre-activation of raw coordinates +-100, which sin(15 z)
+        # turns into 6e-3 rad: a sine model's strict precision is f32 - render.grid_precision picks it)
+        assert rel_l2(m(x).cpu().numpy(), g["y"]) < (5e-5 if act == "tanh" else 3e-3)
         m.precision = "f16"
         assert rel_l2(m(x).cpu().numpy(), g["y"]) < (3e-3 if act == "tanh" else 3e-2)      # sin(15 z): f16 operands in front of a steep argument
         m.precision = "f32"

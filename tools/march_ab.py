@@ -5,7 +5,7 @@ import os, sys, json, tempfile
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from nerf_for_angiography_amd.nerf.run_nerf_acc import main
 out = {}
-for march in ("dense", "grid"):
+for march in ("dense", "grid", "grid_ops"):
     d = tempfile.mkdtemp(prefix="afx_march_")
     r = main(["--synthetic", "--img_size", "100", "--number_angles", "3", "--limited_size", "90", "--n_iters", "1500",
               "--display_every", "500", "--sample_size", "75", "--depth_samples", "300", "--num_layers", "4",
