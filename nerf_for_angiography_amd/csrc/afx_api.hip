@@ -797,7 +797,7 @@ extern "C" int afx_pack_groups(const int64_t* offsets, const int64_t* group_offs
                                float* ts_pad, float* te_pad, int32_t* group_ray, void* stream) {
   if (n_rays <= 0) return AFX_OK;
   if (!offsets || !group_offsets || !ts_pad || !te_pad || !group_ray) return fail(AFX_E_INVALID, "afx_pack_groups: null argument");
-  hipLaunchKernelGGL(k_pack_groups, dim3((unsigned)((n_rays + 63) / 64)), dim3(64), 0, (hipStream_t)stream, offsets, group_offsets, n_rays, t_starts, t_ends,
+  hipLaunchKernelGGL(k_pack_groups, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, (hipStream_t)stream, offsets, group_offsets, n_rays, t_starts, t_ends,
                      ts_pad, te_pad, group_ray);
   HIPCHK(hipGetLastError());
   return AFX_OK;
@@ -1029,7 +1029,7 @@ extern "C" int afx_march_count(const afx_march_args* args, int32_t* counts, void
   if (int rc = fill_march(args, a, "afx_march_count")) return rc;
   if (a.n_rays == 0) return AFX_OK;
   if (!counts) return fail(AFX_E_INVALID, "afx_march_count: null counts");
-  hipLaunchKernelGGL(k_march_count, blocks_for(a.n_rays, 64), dim3(64), 0, (hipStream_t)stream, a, counts);
+  hipLaunchKernelGGL(k_march_count, blocks_for(a.n_rays, 4), dim3(256), 0, (hipStream_t)stream, a, counts);
   HIPCHK(hipGetLastError());
   return AFX_OK;
 }
@@ -1040,7 +1040,7 @@ extern "C" int afx_march_write(const afx_march_args* args, const int64_t* offset
   if (int rc = fill_march(args, a, "afx_march_write")) return rc;
   if (a.n_rays == 0) return AFX_OK;
   if (!offsets || !ray_indices || !t_starts || !t_ends) return fail(AFX_E_INVALID, "afx_march_write: null argument");
-  hipLaunchKernelGGL(k_march_write, blocks_for(a.n_rays, 64), dim3(64), 0, (hipStream_t)stream, a, offsets, ray_indices, t_starts, t_ends, mid_points);
+  hipLaunchKernelGGL(k_march_write, blocks_for(a.n_rays, 4), dim3(256), 0, (hipStream_t)stream, a, offsets, ray_indices, t_starts, t_ends, mid_points);
   HIPCHK(hipGetLastError());
   return AFX_OK;
 }
@@ -1049,7 +1049,7 @@ extern "C" int afx_march_visibility(const float* raw, int32_t input_is_alpha, co
                                     int64_t n_rays, float early_stop_eps, float alpha_thre, uint8_t* keep, int32_t* counts, void* stream) {
   if (n_rays <= 0) return AFX_OK;
   if (!offsets || !keep || !counts) return fail(AFX_E_INVALID, "afx_march_visibility: null argument");
-  hipLaunchKernelGGL(k_march_visibility, blocks_for(n_rays, 64), dim3(64), 0, (hipStream_t)stream, raw, (int)input_is_alpha, t_starts, t_ends, offsets, n_rays,
+  hipLaunchKernelGGL(k_march_visibility, blocks_for(n_rays, 4), dim3(256), 0, (hipStream_t)stream, raw, (int)input_is_alpha, t_starts, t_ends, offsets, n_rays,
                      early_stop_eps, alpha_thre, keep, counts);
   HIPCHK(hipGetLastError());
   return AFX_OK;
@@ -1060,7 +1060,7 @@ extern "C" int afx_march_compact(const uint8_t* keep, const int64_t* offsets_in,
                                  float* t_ends_out, void* stream) {
   if (n_rays <= 0) return AFX_OK;
   if (!keep || !offsets_in || !offsets_out) return fail(AFX_E_INVALID, "afx_march_compact: null argument");
-  hipLaunchKernelGGL(k_march_compact, blocks_for(n_rays, 64), dim3(64), 0, (hipStream_t)stream, keep, offsets_in, offsets_out, n_rays,
+  hipLaunchKernelGGL(k_march_compact, blocks_for(n_rays, 4), dim3(256), 0, (hipStream_t)stream, keep, offsets_in, offsets_out, n_rays,
                      t_starts_in, t_ends_in, ray_indices_out, t_starts_out, t_ends_out);
   HIPCHK(hipGetLastError());
   return AFX_OK;

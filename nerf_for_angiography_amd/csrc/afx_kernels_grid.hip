@@ -192,85 +192,135 @@ __device__ __forceinline__ bool march_keep(const MarchArgs& a, const float o[3],
   if (!grid_cell(a.g, __fadd_rn(o[0], __fmul_rn(d[0], m)), __fadd_rn(o[1], __fmul_rn(d[1], m)), __fadd_rn(o[2], __fmul_rn(d[2], m)), idx)) return false;
   return (a.bits[idx >> 5] >> (idx & 31)) & 1u;
 }
+// The five per-ray kernels below run ONE WAVEFRONT PER RAY (blocks of 256 threads = 4 rays): the 64 lanes take 64 consecutive steps /
+// samples of the ray at a time, compaction offsets come from a ballot + prefix population count, so the writes of a chunk are
+// contiguous and the arithmetic per step is exactly the one-thread-per-ray version's (same expressions, same order where order matters).
+// (One thread per ray left 5 625 rays x 300 dependent steps on 88 wavefronts: 0.66 ms of a 2.1 ms training iteration.)
+__device__ __forceinline__ int lane_prefix(uint64_t ballot) {      // kept lanes below this one
+  return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0u));
+}
 // pass 1: kept steps per ray.  pass 2 (offsets = exclusive scan of the counts): packed (ray_indices, t_starts, t_ends[, mid-points]).
-__global__ void k_march_count(const MarchArgs a, int32_t* counts) {
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(256) k_march_count(const MarchArgs a, int32_t* counts) {
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (r >= a.n_rays) return;
   float o[3], d[3], tmin;
   int ns;
   march_range(a, r, o, d, tmin, ns);
   int c = 0;
-  for (int k = 0; k < ns; ++k) {
-    const float ts = __fadd_rn(tmin, __fmul_rn((float)k, a.dt)), te = __fadd_rn(ts, a.dt);
-    c += march_keep(a, o, d, ts, te) ? 1 : 0;
+  for (int k0 = 0; k0 < ns; k0 += 64) {
+    const int k = k0 + lane;
+    bool keep = false;
+    if (k < ns) {
+      const float ts = __fadd_rn(tmin, __fmul_rn((float)k, a.dt)), te = __fadd_rn(ts, a.dt);
+      keep = march_keep(a, o, d, ts, te);
+    }
+    c += __popcll(__ballot(keep));
   }
-  counts[r] = c;
+  if (lane == 0) counts[r] = c;
 }
-__global__ void k_march_write(const MarchArgs a, const int64_t* offsets, int32_t* ray_indices, float* t_starts, float* t_ends, float* mid_pts) {
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(256) k_march_write(const MarchArgs a, const int64_t* offsets, int32_t* ray_indices, float* t_starts, float* t_ends, float* mid_pts) {
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (r >= a.n_rays) return;
   float o[3], d[3], tmin;
   int ns;
   march_range(a, r, o, d, tmin, ns);
-  int64_t w = offsets[r];
-  for (int k = 0; k < ns; ++k) {
-    const float ts = __fadd_rn(tmin, __fmul_rn((float)k, a.dt)), te = __fadd_rn(ts, a.dt);
-    if (!march_keep(a, o, d, ts, te)) continue;
-    ray_indices[w] = (int32_t)r; t_starts[w] = ts; t_ends[w] = te;
-    if (mid_pts) {
-      // positions = o + d * (t_s + t_e) / 2.0   (alpha_fn, nerf_helpers_acc.py:13-15)
-      const float s = __fadd_rn(ts, te);
-#pragma unroll
-      for (int q = 0; q < 3; ++q) mid_pts[3 * w + q] = __fadd_rn(o[q], __fdiv_rn(__fmul_rn(d[q], s), 2.0f));
+  int64_t base = offsets[r];
+  for (int k0 = 0; k0 < ns; k0 += 64) {
+    const int k = k0 + lane;
+    bool keep = false;
+    float ts = 0.f, te = 0.f;
+    if (k < ns) {
+      ts = __fadd_rn(tmin, __fmul_rn((float)k, a.dt));
+      te = __fadd_rn(ts, a.dt);
+      keep = march_keep(a, o, d, ts, te);
     }
-    ++w;
+    const uint64_t bal = __ballot(keep);
+    if (keep) {
+      const int64_t w = base + lane_prefix(bal);
+      ray_indices[w] = (int32_t)r; t_starts[w] = ts; t_ends[w] = te;
+      if (mid_pts) {
+        // positions = o + d * (t_s + t_e) / 2.0   (alpha_fn, nerf_helpers_acc.py:13-15)
+        const float sm = __fadd_rn(ts, te);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) mid_pts[3 * w + q] = __fadd_rn(o[q], __fdiv_rn(__fmul_rn(d[q], sm), 2.0f));
+      }
+    }
+    base += __popcll(bal);
   }
 }
 // alpha of the candidates from the raw MLP output: 1 - exp(-sigmoid(raw) * (t_e - t_s))  (alpha_fn, nerf_helpers_acc.py:19-23),
 // then nerfacc's render_visibility per ray over its packed segment: steps with alpha < alpha_thre are skipped WITHOUT
 // attenuating T; the ray stops once T < early_stop_eps.  keep[i] in {0,1}; counts[r] = kept steps of ray r.
-__global__ void k_march_visibility(const float* raw, int is_alpha, const float* t_starts, const float* t_ends, const int64_t* offsets, int64_t n_rays,
-                                   float early_stop_eps, float alpha_thre, uint8_t* keep, int32_t* counts) {
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// The 64 lanes form the alphas of 64 samples at once (the transcendental part); the transmittance product then runs over them IN ORDER
+// (wave-uniform loop of lane broadcasts: the same multiplications in the same order as a sequential march, so the kept set is the same bit for bit).
+__global__ void __launch_bounds__(256) k_march_visibility(const float* raw, int is_alpha, const float* t_starts, const float* t_ends, const int64_t* offsets, int64_t n_rays,
+                                                          float early_stop_eps, float alpha_thre, uint8_t* keep, int32_t* counts) {
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (r >= n_rays) return;
+  const int64_t i0 = offsets[r], i1 = offsets[r + 1];
   float T = 1.f;
   int c = 0;
-  for (int64_t i = offsets[r]; i < offsets[r + 1]; ++i) {
-    uint8_t k = 0;
-    if (!(T < early_stop_eps)) {
-      float alpha = raw[i];           // is_alpha: the caller's alpha_fn output
+  for (int64_t b = i0; b < i1; b += 64) {
+    const int64_t i = b + lane;
+    float alpha = 0.f;
+    if (i < i1) {
+      alpha = raw[i];           // is_alpha: the caller's alpha_fn output
       if (!is_alpha) {
-        const float sg = 1.f / (1.f + expf(-raw[i]));
+        const float sg = 1.f / (1.f + expf(-alpha));
         alpha = 1.f - expf(-__fmul_rn(sg, __fsub_rn(t_ends[i], t_starts[i])));
       }
-      if (!(alpha < alpha_thre)) { k = 1; T = __fmul_rn(T, 1.f - alpha); }
     }
-    keep[i] = k;
-    c += k;
+    const bool thick = i < i1 && !(alpha < alpha_thre);
+    const uint64_t tb = __ballot(thick);
+    const int nn = (int)((i1 - b) < 64 ? (i1 - b) : 64);
+    bool mine = false;
+    for (int j = 0; j < nn; ++j) {                 // wave-uniform: T is the same in every lane
+      if (T < early_stop_eps) break;
+      if ((tb >> j) & 1ull) {
+        if (j == lane) mine = true;
+        T = __fmul_rn(T, 1.f - __shfl(alpha, j));
+      }
+    }
+    if (i < i1) keep[i] = mine ? 1 : 0;
+    c += __popcll(__ballot(mine));
   }
-  counts[r] = c;
+  if (lane == 0) counts[r] = c;
 }
-__global__ void k_march_compact(const uint8_t* keep, const int64_t* offsets_in, const int64_t* offsets_out, int64_t n_rays,
-                                const float* ts_in, const float* te_in, int32_t* ri_out, float* ts_out, float* te_out) {
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(256) k_march_compact(const uint8_t* keep, const int64_t* offsets_in, const int64_t* offsets_out, int64_t n_rays,
+                                                       const float* ts_in, const float* te_in, int32_t* ri_out, float* ts_out, float* te_out) {
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (r >= n_rays) return;
   int64_t w = offsets_out[r];
-  for (int64_t i = offsets_in[r]; i < offsets_in[r + 1]; ++i)
-    if (keep[i]) { ri_out[w] = (int32_t)r; ts_out[w] = ts_in[i]; te_out[w] = te_in[i]; ++w; }
+  const int64_t i1 = offsets_in[r + 1];
+  for (int64_t b = offsets_in[r]; b < i1; b += 64) {
+    const int64_t i = b + lane;
+    const bool k = i < i1 && keep[i] != 0;
+    const uint64_t bal = __ballot(k);
+    if (k) {
+      const int64_t o = w + lane_prefix(bal);
+      ri_out[o] = (int32_t)r; ts_out[o] = ts_in[i]; te_out[o] = te_in[i];
+    }
+    w += __popcll(bal);
+  }
 }
 
 // Group-aligned copy of a packed, ray-sorted sample list for the fused packed training step: ray r's samples start at padded index
 // 32 goff[r] (goff = exclusive scan of ceil(count / 32)); the rest of its last 32-sample group is dead padding (ts = te = 0); group_ray[g] = r.
-__global__ void k_pack_groups(const int64_t* offsets, const int64_t* goff, int64_t n_rays, const float* ts_in, const float* te_in,
-                              float* ts_pad, float* te_pad, int32_t* group_ray) {
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(256) k_pack_groups(const int64_t* offsets, const int64_t* goff, int64_t n_rays, const float* ts_in, const float* te_in,
+                                                     float* ts_pad, float* te_pad, int32_t* group_ray) {
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (r >= n_rays) return;
   const int64_t i0 = offsets[r], cnt = offsets[r + 1] - i0, g0 = goff[r], g1 = goff[r + 1];
-  for (int64_t k = 0; k < (g1 - g0) * 32; ++k) {
+  for (int64_t k = lane; k < (g1 - g0) * 32; k += 64) {
     ts_pad[g0 * 32 + k] = k < cnt ? ts_in[i0 + k] : 0.f;
     te_pad[g0 * 32 + k] = k < cnt ? te_in[i0 + k] : 0.f;
   }
-  for (int64_t g = g0; g < g1; ++g) group_ray[g] = (int32_t)r;
+  for (int64_t g = g0 + lane; g < g1; g += 64) group_ray[g] = (int32_t)r;
 }
 
 // --- device ray sampler (sample_pixel_rays, nerf/nerf_helpers.py:137-150): weighted sampling WITHOUT replacement of k of n

@@ -120,8 +120,14 @@ class Engine:
                 raise AfxError("the workspace must be sized before graph capture: run the same call once eagerly first")
             if self._ws is not None and self._ws_captured:
                 self._retired.append(self._ws)
+            # a request that outgrows the buffer gets 25 % head-room (within the cap): the packed / points paths ask for a slightly different
+            # size every iteration, and a hipMalloc per new maximum (several ms at GB sizes) would dominate them
+            grow = self._ws is not None and self._ws.device == device
             self._ws = None
-            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            size = int(nbytes)
+            if grow:
+                size = max(size, min(int(size * 1.25), max(self.max_workspace_bytes, size)))
+            self._ws = torch.empty(size, dtype=torch.uint8, device=device)
             self._ws_captured = False
         if capturing:
             self._ws_captured = True
