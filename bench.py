@@ -321,8 +321,8 @@ def main():
                 "step_tflops_algorithmic": round((fwd_f + dgrad_f + wgrad_f) * value / world / 1e12, 2),
                 "step_frac_of_peak": round((fwd_f + dgrad_f + wgrad_f) * value / world / 1e12 / peak, 4)}
     # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of THIS round's code
-    # (profiles/r02_pmc_traffic.json names the commit they ran at); only valid for the configuration those passes ran
-    traffic_file = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    # (profiles/r03_pmc_traffic.json names the commit they ran at); only valid for the configuration those passes ran
+    traffic_file = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
     default_cfg = (W, S, args.layers, args.width, fused, abs(args.workspace_gib - 128.0) < 1e-9) == (512, 128, 8, 256, True, True)
     if live[0] is not None:
         roofline["traffic"] = float(live[0])

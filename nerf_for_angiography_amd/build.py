@@ -16,7 +16,8 @@ DEPS = ["afx_api.hip", "afx_kernels_f32.hip", "afx_kernels_bf16.hip", "afx_inst.
 VARIANTS = {"": [], "safe": ["-DAFX_SAFE_WAITS"],
             "window": ["-DAFX_STASH_WINDOW"],     # measurement: stash stores into an L2-resident window (no HBM write stream; wrong results)
             "gaps": ["-DAFX_GAPS=1"],      # A/B: the 8-bit-stash backward kernel with the MFMA-gap schedule (slower)
-            "stamp": ["-DAFX_STAMP", "-DAFX_SINGLE_TU"]}      # diagnostic: per-phase cycle stamps of the backward chain kernel (one translation unit)
+            "stamp": ["-DAFX_STAMP", "-DAFX_SINGLE_TU"],
+            "stamp128": ["-DAFX_STAMP", "-DAFX_STAMP_F=128", "-DAFX_SINGLE_TU"]}      # ... of the width-128 kernels      # diagnostic: per-phase cycle stamps of the backward chain kernel (one translation unit)
 
 
 def lib_path(variant: str = "") -> str:

@@ -181,17 +181,18 @@ extern "C" void afx_destroy(afx_ctx* c) {
   if (!c) return;
 #ifdef AFX_STAMP
   {
-    unsigned long long h[8][8];
+    unsigned long long h[3][8][10];
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps), sizeof(h)) == hipSuccess) {
-      static const char* nm[8] = {"vmcnt wait", "barrier", "request", "fwd mfma", "fwd epilogue", "bwd mfma", "bwd epilogue", "other"};
-      for (int w = 0; w < 8; ++w) {
-        unsigned long long tot = 0;
-        for (int i = 0; i < 8; ++i) tot += h[w][i];
-        if (!tot) continue;
-        fprintf(stderr, "[stamps] wave %d total %llu:", w, tot);
-        for (int i = 0; i < 8; ++i) fprintf(stderr, " %s %.1f%%", nm[i], 100.0 * h[w][i] / tot);
-        fprintf(stderr, "\n");
-      }
+      static const char* nm[10] = {"vmcnt wait", "barrier", "request", "fwd mfma", "fwd epilogue", "bwd mfma", "bwd epilogue", "other", "tile prologue", "output/sums/masks"};
+      for (int p = 0; p < 3; ++p)
+        for (int w = 0; w < 8; ++w) {
+          unsigned long long tot = 0;
+          for (int i = 0; i < 10; ++i) tot += h[p][w][i];
+          if (!tot) continue;
+          fprintf(stderr, "[stamps] phase %d wave %d total %llu:", p, w, tot);
+          for (int i = 0; i < 10; ++i) fprintf(stderr, " %s %.1f%%", nm[i], 100.0 * h[p][w][i] / tot);
+          fprintf(stderr, "\n");
+        }
     }
   }
 #endif

@@ -178,8 +178,11 @@ __device__ __forceinline__ unsigned halfmask(unsigned b, int q) {
 __device__ __forceinline__ unsigned mask_expand(unsigned b16) { return (b16 & 0xffu) | ((b16 & 0xff00u) << 8); }
 
 #ifdef AFX_STAMP      // diagnostic build only: per-phase cycle totals of workgroup 0's waves (s_memtime), read back by afx_destroy
-__device__ unsigned long long g_stamps[8][8];
-#define STAMP(i) do { if (BWD && NW == 8 && F == 256) { const uint64_t t_ = __builtin_amdgcn_s_memtime(); ph[i] += t_ - tlast; tlast = t_; } } while (0)
+#ifndef AFX_STAMP_F
+#define AFX_STAMP_F 256      // the layer width whose backward-family kernels are stamped (-DAFX_STAMP_F=128 for the reference's default model)
+#endif
+__device__ unsigned long long g_stamps[3][8][10];      // [PHASE][wave][phase of the tile]
+#define STAMP(i) do { if (BWD && NW == 8 && F == AFX_STAMP_F) { const uint64_t t_ = __builtin_amdgcn_s_memtime(); ph[i] += t_ - tlast; tlast = t_; } } while (0)
 #else
 #define STAMP(i) do { } while (0)
 #endif
@@ -251,7 +254,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
 
   // A step covers TPS consecutive 32-row output tiles of one layer: one barrier and one LDS-DMA batch per step.
 #ifdef AFX_STAMP
-  uint64_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   uint64_t tlast = __builtin_amdgcn_s_memtime();
 #endif
   constexpr int TPS = chain_tps(NT, BWD, X3);
@@ -582,6 +585,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
       __builtin_amdgcn_sched_barrier(0);
     };
 
+    STAMP(8);      // tile prologue: samples, first-layer fragments
     if constexpr (!P2) {      // ======== forward half
     // ---------------- layer 0 (always split: hi*hi + hi*lo + lo*hi)
     {
@@ -843,6 +847,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
         __builtin_amdgcn_global_load_lds(GPTR(mg + off + lane * 16), LPTR((char*)mk16 + off), 16, 0, 0);
       asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     }
+    STAMP(9);      // output layer, compositing, output-layer sums, mask copy / load
     if constexpr (BWD && !P1) {
       // ---------------- input-gradient chain, 16-bit operands, fp32 accumulate.  bf16: dZ_l.  H16: J_l = dZ_l / g.
       u32x4 dz[NCG][NT][2];
@@ -1029,8 +1034,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef AFX_STAMP
-  if (BWD && NW == 8 && F == 256 && blockIdx.x == 0 && lane == 0)
-    for (int i = 0; i < 8; ++i) g_stamps[wave][i] += ph[i];
+  if (BWD && NW == 8 && F == AFX_STAMP_F && blockIdx.x == 0 && lane == 0)
+    for (int i = 0; i < 10; ++i) g_stamps[PHASE][wave][i] += ph[i];
 #endif
 }
 

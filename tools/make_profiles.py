@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """profiles/<tag>_<prec>_kernel_stats.md, profiles/<tag>_<prec>_pmc.md, profiles/<tag>_pmc_traffic.json and
 profiles/<tag>_bench_<prec>.json from the reduced rocprofv3 outputs in gpurun_out/ (written by tools/profile_round.sh
-through tools/pmc_reduce.py).  usage: make_profiles.py [prec=f16s8] [tag=r02]"""
+through tools/pmc_reduce.py).  usage: make_profiles.py [prec=f16s8] [tag=r03]"""
 import json, os, subprocess, sys
 
 P = sys.argv[1] if len(sys.argv) > 1 else "f16s8"
-T = sys.argv[2] if len(sys.argv) > 2 else "r02"
+T = sys.argv[2] if len(sys.argv) > 2 else "r03"
 G = "gpurun_out"
 load = lambda n: json.load(open(f"{G}/{T}_{P}_{n}.json"))
 st = load("stats")["kernel_stats"]

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Round profile (run on the GPU box through gpurun): kernel stats, HBM-traffic PMC passes, SQ/MFMA PMC passes,
 # bench JSONs.  Outputs land under gpurun_out/ and are reduced by tools/pmc_reduce.py / tools/make_profiles.py.
-# usage: tools/profile_round.sh [precision=f16s8] [tag=r02]
+# usage: tools/profile_round.sh [precision=f16s8] [tag=r03]
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 P=${1:-f16s8}
-T=${2:-r02}
+T=${2:-r03}
 O=gpurun_out
 set -x
 python3 bench.py --precision $P > $O/${T}_bench_$P.log 2>&1 && grep "^{" $O/${T}_bench_$P.log | tail -1 > $O/${T}_bench_$P.json
