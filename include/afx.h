@@ -245,6 +245,19 @@ int afx_fine_depths(const float* z_coarse, int z_per_ray, const float* w_coarse,
 int afx_fine_depths_from_tau(const float* z_coarse, int z_per_ray, const float* tau_coarse, const float* u, int64_t n_rays,
                              int32_t n_coarse, int32_t n_fine, float* z_out, void* stream);
 
+/* The hierarchical training step `fine_sampling` belongs to (nerf/nerf_helpers.py:178-195: coarse pass, sample_pdf on its weights, re-evaluation
+ * of all S + N_f depths, compositing, MSE, backward through the fine pass), WITHOUT evaluating the coarse depths twice: coarse and fine network
+ * are the same model here (fine_model = None, `:190`), and the coarse depths are a subset of the merged ones, so the coarse pass runs as the
+ * forward HALF of the training kernel over the S coarse depths (stash, masks, sigma, tau), sample_pdf draws the N_f new depths from its weights, a
+ * second forward half evaluates ONLY those, a per-ray kernel composites the merged list (step lengths of the merged order, last 1e10, x ||d||),
+ * forms pixel, the MSE gradient and every sample's finished dL/draw, and the two backward halves + weight gradients follow.  The samples are
+ * detached as upstream (`:186`).  args: rays (either ray mode), depth_mode AFX_DEPTH_SHARED_Z / PER_RAY_Z with the COARSE depths z, n_samples = S,
+ * pixel out [R], workspace of afx_hier_workspace_bytes (fewer bytes: more ray chunks).  u[R, n_fine]: the uniform draws of sample_pdf.
+ * z_all: optional out [R, S + n_fine], the merged depths.  AFX_PREC_F16S8, ReLU, no input encoding. */
+int64_t afx_hier_workspace_bytes(const afx_ctx* ctx, int64_t n_rays, int32_t n_coarse, int32_t n_fine);
+int afx_hier_train_step_mse(afx_ctx* ctx, int prec, const void* prepared, const afx_render_args* args, int32_t n_fine, const float* u,
+                            const float* target, float inv_n, float* z_all, float* grad_flat, void* stream);
+
 /* Ground-truth projector ray_tracing(interpolator, ...) — phantomdata/helpers.py:192-224 — for a voxel volume
  * vol[nx,ny,nz] (C order) on the regular grid axis_k = origin_k + i*spacing_k, trilinear interpolation with
  * `fill_value` outside (scipy RegularGridInterpolator(method='linear', bounds_error=False, fill_value) as built by

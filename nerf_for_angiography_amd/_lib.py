@@ -81,6 +81,9 @@ _SIGS = {
     "afx_grid_update": (C.c_int, [C.POINTER(GridDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_float, C.c_void_p]),
     "afx_grid_binarize": (C.c_int, [C.POINTER(GridDesc), C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "afx_grid_pack": (C.c_int, [C.POINTER(GridDesc), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "afx_hier_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32]),
+    "afx_hier_train_step_mse": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(RenderArgs), C.c_int32, C.c_void_p, C.c_void_p, C.c_float,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]),
     "afx_pack_groups": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "afx_train_step_packed_mse": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -336,7 +336,7 @@ extern "C" int afx_prepare_weights(afx_ctx* c, int prec, const float* params, co
   const PrepLayout L = prep_layout(c, prec);
   if (prepared_bytes < L.total) return fail(AFX_E_WORKSPACE, "afx_prepare_weights: prepared buffer %zu < %zu bytes", prepared_bytes, L.total);
   if (int rc = check_dev(c, "afx_prepare_weights")) return rc;
-  PrepArgs p;
+  PrepArgs p = {};
   p.params = params; p.enc_aux = enc_aux; p.prepared = (char*)prepared;
   p.F = c->d.width; p.n_hidden = c->d.n_hidden; p.k0 = c->k0; p.nq = c->nq; p.enc = c->d.enc; p.n_freq = c->d.n_freq;
   p.small_off = L.small_off; p.slab0_off = L.slab0_off; p.fwd_off = L.fwd_off; p.bwd_off = L.bwd_off;
@@ -344,7 +344,7 @@ extern "C" int afx_prepare_weights(afx_ctx* c, int prec, const float* params, co
   p.weights = prec == AFX_PREC_F32 ? 1 : 0;
   hipLaunchKernelGGL(k_prepare_f32, dim3(512), dim3(256), 0, (hipStream_t)stream, p);
   if (is_bf16(prec)) {
-    PrepArgs16 q;
+    PrepArgs16 q = {};
     q.params = params; q.prepared = (char*)prepared;
     q.F = c->d.width; q.n_hidden = c->d.n_hidden; q.k0 = c->k0; q.nk0 = nk0_of(c); q.parts = prec == AFX_PREC_BF16X3 ? 2 : 1;
     q.slab0_off = L.slab0_off; q.slab0_bytes = L.slab0_bytes; q.fwd_off = L.fwd_off; q.slabh_stride = L.slabh_stride;
@@ -564,6 +564,7 @@ static int launch_wgrad8_t(afx_ctx* c, const WgradArgs& w, const ReduceArgs& rd,
     hipLaunchKernelGGL(k_wgrad_s8<F>, dim3(w.n_splits, N + (w.enc16 ? 1 + (w.coef_cols > 0 ? 1 : 0) : 0)), dim3(512), lds, st, w);
   }
   hipLaunchKernelGGL(k_small_from_groups<F>, dim3(rd.n_small), dim3(F), 0, st, w);
+  if (w.no_sw) hipLaunchKernelGGL(k_wout_stash8<F>, dim3(rd.n_small), dim3(2 * F), 0, st, w);      // output layer from the stash of H_N (same records)
   hipLaunchKernelGGL(k_reduce_w<F>, dim3((F * F + 255) / 256, N + 1), dim3(256), 0, st, rd);
   hipLaunchKernelGGL(k_reduce_b<F>, dim3(1, N + 2), dim3(F), 0, st, rd);
   hipLaunchKernelGGL(k_reduce_small<F>, dim3((unsigned)((F * rd.k0pad + 2 * F + 1 + 63) / 64)), dim3(64, 4), 0, st, rd);
@@ -702,7 +703,7 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
       HIPCHK(hipStreamWaitEvent(c->side, c->ev_chain[bI], 0));
       ws_st = c->side;
     }
-    WgradArgs w;
+    WgradArgs w = {};      // (zero: fields a path does not use must read as "off")
     w.stash_h = a.stash_h; w.stash_dz = a.stash_dz; w.stash_e = a.stash_e; w.graw = a.graw;
     w.rows = (t1 - t0) * TILE;
     w.stride_rows = (int64_t)rows;   // a short last chunk keeps the full-chunk layer stride
@@ -720,7 +721,7 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
     w.gmax = a.gmax; w.stash_esz = (int)esz; w.gexp = a.gexp; w.enc16 = enc16 ? 1 : 0; w.coef_cols = a.coef_cols;
     w.dod = split ? a.dod : nullptr; w.gpr = a.s_pad / GROUP; w.group0 = t0 * (TILE / GROUP); w.group_ray = goff ? a.group_ray : nullptr;
     w.n_groups_valid = goff ? a.n_total / GROUP : n_rays * (int64_t)(a.s_pad / GROUP);
-    ReduceArgs rd;
+    ReduceArgs rd = {};
     rd.partial = partial; rd.partial2 = partial2; rd.n_hidden = N; rd.k0 = c->k0; rd.k0pad = k0ld; rd.n_splits = splits;
     rd.grad = grad_flat; rd.hidden_only = b16 ? 1 : 0; rd.partial_s = partial_s;
     rd.n_small = kSmallBlocks;      // records; every record is written (possibly with zero rows)
@@ -836,6 +837,143 @@ extern "C" int afx_train_step_packed_mse(afx_ctx* c, int prec, const void* prepa
   return run_backward(c, prec, a, dod_bytes + od_bytes, (char*)workspace, workspace_bytes, grad_flat, st, true, n_rays, group_offsets);
 }
 
+// ---- hierarchical training step with coarse re-use
+// Bytes of one sample set of a ray chunk (rows padded to whole tiles): 8-bit H_l and dZ'_l planes (N + 1 each: H_N is stashed here), group exponents,
+// dL/draw per row, the tiles' mask images, the group records.
+static size_t hier_set_bytes(const afx_ctx* c, size_t rows) {
+  const size_t F = c->d.width, N = c->d.n_hidden, tiles = rows / 256;
+  return 2 * (N + 1) * rows * F + rup64(rows * 4, 256) + rows * 4 + tiles * (N + 1) * c->nt * 1024 + rup64((rows / 32) * (3 * F + 8) * 4, 256);
+}
+static size_t hier_fixed_bytes(const afx_ctx* c, int64_t n_rays, int S, int NF) {
+  const size_t F = c->d.width, N = c->d.n_hidden;
+  size_t b = 2 * rup64((size_t)n_rays * S * 4, 256) + 2 * rup64((size_t)n_rays * NF * 4, 256);                    // sigma / tau of the coarse set, new depths, sigma of the new set
+  b += rup64((size_t)n_rays * (size_t)(std::max(s_pad_of(S), s_pad_of(NF)) / GROUP) * 4, 256);                    // optical-depth partials (written by PHASE 1, unused here)
+  b += rup64((N + 2) * (size_t)kSplits * F * F * 4, 256) + rup64((N + 2) * (size_t)kSplits * (F + 4) * 4, 256);
+  b += rup64((size_t)kSmallBlocks * (F * 16 + 2 * F + 4) * 4, 256) + 256;
+  return b;
+}
+
+extern "C" int64_t afx_hier_workspace_bytes(const afx_ctx* c, int64_t n_rays, int32_t n_coarse, int32_t n_fine) {
+  if (!c || n_rays <= 0) return 0;
+  const uint64_t plane_rows = ((uint64_t)1 << 32) / (uint64_t)c->d.width;
+  int64_t nr = (n_rays + 7) / 8 * 8;
+  const int64_t cap = (int64_t)(plane_rows / (uint64_t)s_pad_of(n_coarse)) / 8 * 8;
+  if (nr > cap) nr = cap;
+  return (int64_t)(hier_fixed_bytes(c, n_rays, n_coarse, n_fine) + hier_set_bytes(c, rup64((size_t)nr * s_pad_of(n_coarse), 256)) +
+                   hier_set_bytes(c, rup64((size_t)nr * s_pad_of(n_fine), 256)) + 4096);
+}
+
+extern "C" int afx_hier_train_step_mse(afx_ctx* c, int prec, const void* prepared, const afx_render_args* r, int32_t n_fine, const float* u,
+                                       const float* target, float inv_n, float* z_all, float* grad_flat, void* stream) {
+  if (c && r && r->n_rays == 0) return AFX_OK;
+  int rc = check_render(c, r, "afx_hier_train_step_mse");
+  if (rc) return rc;
+  if (!prepared || !u || !target || !grad_flat || !r->workspace) return fail(AFX_E_INVALID, "afx_hier_train_step_mse: null argument");
+  if (prec != AFX_PREC_F16S8 || c->d.enc != AFX_ENC_NONE || !c->small_in_kernel || c->d.act != AFX_ACT_RELU)
+    return fail(AFX_E_INVALID, "afx_hier_train_step_mse: AFX_PREC_F16S8, ReLU, no input encoding only");
+  if (r->depth_mode != AFX_DEPTH_SHARED_Z && r->depth_mode != AFX_DEPTH_PER_RAY_Z)
+    return fail(AFX_E_INVALID, "afx_hier_train_step_mse: coarse depths z[S] or z[R,S] (dense convention) required");
+  const int S = r->n_samples, NF = n_fine;
+  if (S < 3 || S > AFX_MAX_COARSE || NF < 1 || NF > AFX_MAX_FINE) return fail(AFX_E_INVALID, "afx_hier_train_step_mse: n_coarse in 3..%d, n_fine in 1..%d", AFX_MAX_COARSE, AFX_MAX_FINE);
+  if (NF < 2) return fail(AFX_E_INVALID, "afx_hier_train_step_mse: n_fine must be >= 2");
+  if (int rc2 = check_dev(c, "afx_hier_train_step_mse")) return rc2;
+  hipStream_t st = (hipStream_t)stream;
+  const int F = c->d.width, N = c->d.n_hidden;
+  const int64_t R = r->n_rays, spA = s_pad_of(S), spB = s_pad_of(NF);
+  char* ws = (char*)r->workspace;
+  const size_t fixed = hier_fixed_bytes(c, R, S, NF);
+  if (r->workspace_bytes < fixed + 4096) return fail(AFX_E_WORKSPACE, "afx_hier_train_step_mse: workspace %zu too small", r->workspace_bytes);
+  // rays per chunk: a multiple of 8 (so that a chunk's first sample of either set starts a 256-sample tile), both sets' planes below 4 GiB
+  const uint64_t plane_rows = ((uint64_t)1 << 32) / (uint64_t)F;
+  int64_t nr = (R + 7) / 8 * 8;
+  nr = std::min<int64_t>(nr, (int64_t)(plane_rows / (uint64_t)spA) / 8 * 8);
+  while (nr >= 8 && fixed + hier_set_bytes(c, rup64((size_t)nr * spA, 256)) + hier_set_bytes(c, rup64((size_t)nr * spB, 256)) + 4096 > r->workspace_bytes) {
+    const int64_t n_chunks = (R + nr - 1) / nr + 1;          // next larger chunk count, equal chunks
+    nr = ((R + n_chunks - 1) / n_chunks + 7) / 8 * 8;
+    if (n_chunks > R) { nr = 0; break; }
+  }
+  if (nr < 8) return fail(AFX_E_WORKSPACE, "afx_hier_train_step_mse: workspace %zu too small for 8 rays per chunk", r->workspace_bytes);
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* p = ws + off; off += rup64(bytes, 256); return p; };
+  float* sigA = (float*)take((size_t)R * S * 4);  float* tauA = (float*)take((size_t)R * S * 4);
+  float* zf = (float*)take((size_t)R * NF * 4);   float* sigB = (float*)take((size_t)R * NF * 4);
+  float* od_part = (float*)take((size_t)R * (size_t)(std::max(spA, spB) / GROUP) * 4);
+  float* partial = (float*)take((size_t)(N + 2) * kSplits * F * F * 4);
+  float* partial2 = (float*)take((size_t)(N + 2) * kSplits * (F + 4) * 4);
+  float* partial_s = (float*)take((size_t)kSmallBlocks * (F * 16 + 2 * F + 4) * 4);
+  uint32_t* gmax = (uint32_t*)take(256);
+  struct SetBuf { char *stash_h, *stash_dz, *gexp, *masks; float *gpart, *records; size_t rows; };
+  auto carve = [&](size_t rows) {
+    SetBuf b; b.rows = rows;
+    b.stash_h = take((size_t)(N + 1) * rows * F); b.stash_dz = take((size_t)(N + 1) * rows * F);
+    b.gexp = take(rows * 4); b.gpart = (float*)take(rows * 4);
+    b.masks = take((rows / 256) * (size_t)(N + 1) * c->nt * 1024);
+    b.records = (float*)take((rows / 32) * (size_t)(3 * F + 8) * 4);
+    return b;
+  };
+  const SetBuf A = carve(rup64((size_t)nr * spA, 256)), B = carve(rup64((size_t)nr * spB, 256));
+  if (off > r->workspace_bytes) return fail(AFX_E_WORKSPACE, "afx_hier_train_step_mse: workspace layout exceeds the buffer (%zu > %zu)", off, r->workspace_bytes);
+
+  ChainArgs base = {};
+  fill_model(c, prec, true, prepared, base);
+  fill_render(r, base);
+  base.fused = 0; base.stash8 = 1; base.coef_cols = 0; base.debug = 0; base.persistent = 1;
+  base.od_part = od_part; base.gmax = gmax; base.defer_out = 1; base.dod = nullptr; base.pixel = r->pixel;
+  auto set_args = [&](const ChainArgs& src, const SetBuf& b, int64_t r0, int64_t r1, int64_t sp) {
+    ChainArgs a = src;
+    a.tile0 = (int)(r0 * sp / 256); a.tile1 = (int)((r1 * sp + 255) / 256);
+    a.stash_h = (float*)b.stash_h; a.stash_dz = (float*)b.stash_dz; a.stash_e = nullptr; a.graw = (float*)b.gexp; a.gexp = (int32_t*)b.gexp;
+    a.gpart = b.gpart; a.masks = b.masks; a.small_part = b.records; a.stash_rows = (int64_t)b.rows;
+    return a;
+  };
+  ChainArgs argsA = base;                     // the coarse set: the caller's depths
+  argsA.sigma = sigA; argsA.tau = tauA;
+  ChainArgs argsB = base;                     // the new set: per-ray depths zf[R, NF]
+  argsB.depth_mode = AFX_DEPTH_PER_RAY_Z; argsB.z = zf; argsB.n_samples = NF; argsB.s_pad = (int)spB; argsB.n_total = R * spB;
+  argsB.sigma = sigB; argsB.tau = nullptr;
+  auto wgrad_set = [&](const ChainArgs& a, const SetBuf& b) -> int {
+    WgradArgs w = {};
+    w.stash_h = a.stash_h; w.stash_dz = a.stash_dz; w.stash_e = nullptr; w.graw = a.graw;
+    w.rows = (int64_t)(a.tile1 - a.tile0) * 256; w.stride_rows = (int64_t)b.rows;
+    w.n_hidden = N; w.k0 = c->k0; w.k0pad = 16;
+    int splits = c->n_cu / N;
+    if (splits > (int)(w.rows / 256)) splits = (int)(w.rows / 256);
+    if (splits < 1) splits = 1;
+    if (splits > kSplits) splits = kSplits;
+    w.n_splits = splits;
+    w.rows_per_split = (int)(((w.rows + splits - 1) / splits + 63) / 64 * 64);
+    w.partial = partial; w.partial2 = partial2; w.partial_s = partial_s; w.debug = 0; w.small_groups = 1;
+    w.gmax = gmax; w.stash_esz = 1; w.gexp = a.gexp; w.enc16 = 0; w.coef_cols = 0;
+    w.dod = nullptr; w.gpr = 1; w.group0 = 0; w.n_groups_valid = 0; w.group_ray = nullptr;
+    w.records = b.records; w.no_sw = 1; w.gfull = b.gpart;
+    ReduceArgs rd = {};
+    rd.partial = partial; rd.partial2 = partial2; rd.n_hidden = N; rd.k0 = c->k0; rd.k0pad = 16; rd.n_splits = splits;
+    rd.grad = grad_flat; rd.hidden_only = 1; rd.partial_s = partial_s; rd.n_small = kSmallBlocks;
+    rd.gmax = gmax; rd.scale_shift = AFX_S8_JSHIFT; rd.layer0_mfma = 0; rd.w0 = nullptr; rd.d_coef = nullptr; rd.coef_cols = 0;
+    return F == 64 ? launch_wgrad8_t<64>(c, w, rd, N, st) : (F == 128 ? launch_wgrad8_t<128>(c, w, rd, N, st) : launch_wgrad8_t<256>(c, w, rd, N, st));
+  };
+  for (int64_t r0 = 0; r0 < R; r0 += nr) {
+    const int64_t r1 = std::min<int64_t>(r0 + nr, R), n = r1 - r0;
+    const ChainArgs a = set_args(argsA, A, r0, r1, spA), b = set_args(argsB, B, r0, r1, spB);
+    // coarse set: forward half (H_l incl. H_N, masks, sigma, tau) -> the new depths -> new set: forward half -> per-ray composite of both
+    if ((rc = launch_chain(c, prec, true, a, st, 1))) return rc;
+    hipLaunchKernelGGL(k_fine_depths, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, r->depth_mode == AFX_DEPTH_PER_RAY_Z ? r->z + r0 * S : r->z,
+                       r->depth_mode == AFX_DEPTH_PER_RAY_Z ? 1 : 0, (const float*)nullptr, (const float*)(tauA + r0 * S), u + r0 * NF, n, S, NF,
+                       (float*)nullptr, zf + r0 * NF);
+    if ((rc = launch_chain(c, prec, true, b, st, 1))) return rc;
+    hipLaunchKernelGGL(k_hier_composite, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, a, r0, n, (const float*)zf, NF, (const float*)sigA, (const float*)sigB,
+                       target, inv_n, r->pixel, A.gpart, (int)spA, B.gpart, (int)spB, z_all);
+    HIPCHK(hipMemsetAsync(gmax, 0, 4, st));
+    // backward halves (dL/draw per sample comes finished from the composite), then the weight gradients of both sets
+    if ((rc = launch_chain(c, prec, true, a, st, 2))) return rc;
+    if ((rc = launch_chain(c, prec, true, b, st, 2))) return rc;
+    if ((rc = wgrad_set(a, A))) return rc;
+    if ((rc = wgrad_set(b, B))) return rc;
+  }
+  HIPCHK(hipGetLastError());
+  return AFX_OK;
+}
+
 extern "C" int afx_mlp_backward(afx_ctx* c, int prec, const void* prepared, const float* pts, int64_t n_pts,
                                 const float* d_out, float* grad_flat, void* workspace, size_t workspace_bytes, void* stream) {
   if (!c || !prepared || !pts || !d_out || !grad_flat || !workspace) return fail(AFX_E_INVALID, "afx_mlp_backward: null argument");
@@ -863,7 +1001,7 @@ extern "C" int afx_project_volume(const float* vol, int32_t nx, int32_t ny, int3
   a.org = r->origins; a.dir = r->dirs; a.poses = r->ray_mode == AFX_RAYS_POSE ? r->poses : nullptr;
   a.ray_ids = r->ray_ids; a.ray_id0 = r->ray_id0; a.width = r->width; a.height = r->height; a.focal = r->focal;
   a.n_samples = r->n_samples; a.z = r->z; a.n_total = r->n_rays; a.pixel = r->pixel;
-  VolArgs v;
+  VolArgs v = {};
   v.vol = vol; v.nx = nx; v.ny = ny; v.nz = nz; v.x0 = origin[0]; v.y0 = origin[1]; v.z0 = origin[2];
   v.dx = spacing[0]; v.dy = spacing[1]; v.dz = spacing[2]; v.fill = fill_value; v.type_ct = type_ct;
   hipLaunchKernelGGL(k_project_volume, dim3((unsigned)((r->n_rays + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, v);
@@ -924,7 +1062,7 @@ static int fine_depths_impl(const char* who, const float* z_coarse, int z_per_ra
   if (n_fine < 1 || n_fine > AFX_MAX_FINE) return fail(AFX_E_INVALID, "%s: n_fine must be in 1..%d", who, AFX_MAX_FINE);
   if (n_rays <= 0) return AFX_OK;
   hipLaunchKernelGGL(k_fine_depths, dim3((unsigned)((n_rays + 63) / 64)), dim3(64), 0, (hipStream_t)stream, z_coarse, z_per_ray,
-                     w_coarse, tau, u, n_rays, n_coarse, n_fine, z_out);
+                     w_coarse, tau, u, n_rays, n_coarse, n_fine, z_out, (float*)nullptr);
   HIPCHK(hipGetLastError());
   return AFX_OK;
 }
@@ -1026,7 +1164,7 @@ static int fill_march(const afx_march_args* m, MarchArgs& a, const char* who) {
 }
 
 extern "C" int afx_march_count(const afx_march_args* args, int32_t* counts, void* stream) {
-  MarchArgs a;
+  MarchArgs a = {};
   if (int rc = fill_march(args, a, "afx_march_count")) return rc;
   if (a.n_rays == 0) return AFX_OK;
   if (!counts) return fail(AFX_E_INVALID, "afx_march_count: null counts");
@@ -1037,7 +1175,7 @@ extern "C" int afx_march_count(const afx_march_args* args, int32_t* counts, void
 
 extern "C" int afx_march_write(const afx_march_args* args, const int64_t* offsets, int32_t* ray_indices, float* t_starts,
                                float* t_ends, float* mid_points, void* stream) {
-  MarchArgs a;
+  MarchArgs a = {};
   if (int rc = fill_march(args, a, "afx_march_write")) return rc;
   if (a.n_rays == 0) return AFX_OK;
   if (!offsets || !ray_indices || !t_starts || !t_ends) return fail(AFX_E_INVALID, "afx_march_write: null argument");

@@ -82,6 +82,10 @@ struct ChainArgs {
   int32_t stash8;           // f16 mode: 8-bit (bf8) stash of H_l and dZ'_l
   int32_t* gexp;            // 8-bit stash: power-of-two exponent of each 32-sample group's largest |dL/draw| [rows/32]
   int32_t coef_cols;        // 3*n_freq when the fourier coefficients train (the chain kernel then also stashes d(enc)/d(coef)/(2 pi)), else 0
+  // hierarchical step with coarse re-use (afx_hier_train_step_mse): PHASE 1 runs before the samples' final step lengths are known (the fine depths
+  // depend on this very pass): it stashes H_N as well (the output layer's gradient is contracted from the stash later) and forms no g' sums;
+  // PHASE 2 then reads the finished dL/draw per sample from gpart (dod == null)
+  int32_t defer_out;
   // packed, group-aligned samples (AFX_DEPTH_PACKED = 4: the occupancy-grid march's output): sample n of the padded list belongs to ray
   // group_ray[n >> 5]; its interval is [z[n], te[n]) (dead padding slots: te <= ts); optical-depth partials are indexed by group
   const float* te;
@@ -116,6 +120,9 @@ struct WgradArgs {
   // split phases: the output-layer group sums were formed with g' (without the ray's dL/d(optical depth)); k_small_from_groups applies it
   const float* dod;         // [n_rays] or null (fused kernel: the sums already carry it)
   const int32_t* group_ray; // packed samples: ray of each group (then dod[group_ray[g]]), else null (dod[(group0 + g) / gpr])
+  const float* records;     // the group records when they do not lie where H_N's stash would be (hierarchical step with coarse re-use), else null
+  int32_t no_sw;            // hierarchical step with coarse re-use: the group records hold the first-layer sums only (output layer: k_wout_stash8)
+  const float* gfull;       // ... and dL/draw per stash row for k_wout_stash8
   int32_t gpr;              // 32-sample groups per ray (s_pad / 32)
   int64_t group0;           // global index of the chunk's first group
   int64_t n_groups_valid;   // groups that belong to a ray (the chunk's last tile may be padded with dead groups beyond them)

@@ -503,7 +503,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
           }
         }
         if constexpr (S8) {
-          if (l != N && !(GAPS && (l >= 1 || t == NT - 1))) {     // one 16-byte store per tile: chunk 2t + h of the 8-bit layout
+          if ((l != N || (P1 && a.defer_out)) && !(GAPS && (l >= 1 || t == NT - 1))) {     // one 16-byte store per tile: chunk 2t + h of the 8-bit layout
             ++nstores;
             stash_store((char*)a.stash_h + (size_t)l * a.stash_rows * F + (so[cg] + (uint32_t)(2 * t) * 512u), to_bf8x16(nf[0], nf[1], 1.0f));
           }
@@ -736,7 +736,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
       const float raw = d + sm[(N + 2) * F];
       g[cg] = 0.f;
       if constexpr (P2) {      // backward half: dL/draw = dL/d(optical depth of the ray) * g' (PHASE 1 left g' = dt sigma (1 - sigma))
-        g[cg] = sp[cg].live ? a.dod[sp[cg].ray] * a.gpart[m[cg]] : 0.f;
+        g[cg] = sp[cg].live ? (a.dod ? a.dod[sp[cg].ray] : 1.f) * a.gpart[m[cg]] : 0.f;      // (dod null: gpart holds the finished dL/draw)
       } else if (a.mode == 0) {
         if (!BWD) { if (hh == 0 && sp[cg].live) a.out[n[cg]] = a.apply_sigmoid ? sigmoidf_(raw) : raw; }
         else g[cg] = sp[cg].live ? a.dod[n[cg]] : 0.f;
@@ -810,7 +810,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
     }
     if constexpr (SG && !P2) {      // (PHASE 1: g = g', the common factor dod of the group's ray is applied by k_small_from_groups)
 #pragma unroll
-      for (int cg = 0; cg < NCG; ++cg) {
+      for (int cg = 0; cg < (P1 && a.defer_out ? 0 : NCG); ++cg) {
         float* rec = a.small_part + (size_t)(m[cg] >> 5) * (3 * F + 8);
         // g of the 16 sample rows this lane's accumulator registers hold: one exact f32 MFMA, D[n][j] = g_n for all j
         const f32x16 gT = __builtin_amdgcn_mfma_f32_32x32x2f32(hh == 0 ? g[cg] : 0.f, 1.f, (f32x16){0.f}, 0, 0, 0);
@@ -1465,7 +1465,7 @@ __global__ void __launch_bounds__(F) k_small_from_groups(const WgradArgs a) {
   int64_t g0 = (int64_t)blockIdx.x * per, g1 = g0 + per;
   if (g1 > ngroups) g1 = ngroups;
   constexpr int RS = 3 * F + 8;
-  const float* base = (const float*)((const char*)a.stash_h + (size_t)a.n_hidden * a.stride_rows * F * a.stash_esz);
+  const float* base = a.records ? a.records : (const float*)((const char*)a.stash_h + (size_t)a.n_hidden * a.stride_rows * F * a.stash_esz);
   float aw = 0.f, a0 = 0.f, ax = 0.f, ay = 0.f, az = 0.f, sg = 0.f;
 #pragma unroll 4
   for (int64_t g = g0; g < g1; ++g) {
@@ -1477,7 +1477,7 @@ __global__ void __launch_bounds__(F) k_small_from_groups(const WgradArgs a) {
       const int64_t gg = a.group0 + g;
       ds = gg < a.n_groups_valid ? a.dod[a.group_ray ? (int64_t)a.group_ray[gg] : gg / a.gpr] : 0.f;
     }
-    const float sw = rec[p] * ds;
+    const float sw = a.no_sw ? 0.f : rec[p] * ds;
     if (a.enc16) {          // encoded inputs: only the output layer's sums are in the records (first layer: k_wgrad_s8)
       aw += sw;
       sg += rec[3 * F + 6] * ds;
@@ -1491,7 +1491,7 @@ __global__ void __launch_bounds__(F) k_small_from_groups(const WgradArgs a) {
     ax += fmaf(c4[0], s0, c4[3] * s1);
     ay += fmaf(c4[1], s0, d4[0] * s1);
     az += fmaf(c4[2], s0, d4[1] * s1);
-    sg += d4[2] * ds;
+    sg += a.no_sw ? 0.f : d4[2] * ds;
   }
   const size_t SS = (size_t)F * a.k0pad + 2 * F + 4;
   float* P = a.partial_s + (size_t)blockIdx.x * SS;
@@ -1499,8 +1499,52 @@ __global__ void __launch_bounds__(F) k_small_from_groups(const WgradArgs a) {
   P[(size_t)f * a.k0pad + 1] = ay;
   P[(size_t)f * a.k0pad + 2] = az;
   P[(size_t)F * a.k0pad + f] = a0;
+  if (a.no_sw) return;      // the output layer's slots of the record belong to k_wout_stash8
   P[(size_t)F * a.k0pad + F + f] = aw;
   if (p == 0) P[(size_t)F * a.k0pad + 2 * F] = sg;
+}
+
+// Output-layer gradient from the 8-bit stash of H_N (hierarchical step with coarse re-use: dL/draw of a sample is known only after both passes'
+// forward halves, so the chain kernel cannot form sum_n g_n H_N[n] in registers): dW_out[f] = sum_n g_n H_N[n][f], db_out = sum_n g_n.
+// grid = n_small blocks (the record partition of k_small_from_groups: block b owns a contiguous range of 32-sample groups), block = 2 F threads =
+// (32 rows) x (F / 16 chunks): a thread reads one 16-byte chunk (16 stash positions of one sample) per group, converts, scales by the sample's g
+// and accumulates; the 32 rows are summed by lane shuffles; results land in the output-layer slots of the block's partial record.
+template <int F>
+__global__ void __launch_bounds__(2 * F) k_wout_stash8(const WgradArgs a) {
+  const int rr = threadIdx.x & 31, ch = threadIdx.x >> 5;      // row within the group, 16-byte chunk column
+  constexpr int NCH = F / 16;
+  const int64_t ngroups = a.rows >> 5;
+  const int64_t per = (ngroups + gridDim.x - 1) / gridDim.x;
+  int64_t g0 = (int64_t)blockIdx.x * per, g1 = g0 + per;
+  if (g1 > ngroups) g1 = ngroups;
+  const char* hN = (const char*)a.stash_h + (size_t)a.n_hidden * a.stride_rows * F;
+  float acc[16], sg = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  for (int64_t g = g0; g < g1; ++g) {
+    const u32x4 x = *(const u32x4*)(hN + (((size_t)(g * NCH + ch) << 5) + rr) * 16);
+    const float gr = a.gfull[(g << 5) + rr];
+    if (ch == 0) sg += gr;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      acc[4 * q + 0] = fmaf(gr, __builtin_amdgcn_cvt_f32_bf8(x[q], 0), acc[4 * q + 0]);
+      acc[4 * q + 1] = fmaf(gr, __builtin_amdgcn_cvt_f32_bf8(x[q], 1), acc[4 * q + 1]);
+      acc[4 * q + 2] = fmaf(gr, __builtin_amdgcn_cvt_f32_bf8(x[q], 2), acc[4 * q + 2]);
+      acc[4 * q + 3] = fmaf(gr, __builtin_amdgcn_cvt_f32_bf8(x[q], 3), acc[4 * q + 3]);
+    }
+  }
+  const size_t SS = (size_t)F * a.k0pad + 2 * F + 4;
+  float* P = a.partial_s + (size_t)blockIdx.x * SS;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    float v = acc[j];
+#pragma unroll
+    for (int sh = 16; sh >= 1; sh >>= 1) v += __shfl_xor(v, sh);      // the 32 rows of a chunk column are one half-wave
+    if (rr == 0) P[(size_t)F * a.k0pad + F + fperm8(ch * 16 + j)] = v;
+  }
+#pragma unroll
+  for (int sh = 16; sh >= 1; sh >>= 1) sg += __shfl_xor(sg, sh);
+  if (threadIdx.x == 0) P[(size_t)F * a.k0pad + 2 * F] = sg;
 }
 
 // grid = ceil(SS/64) blocks of 64 x 4 threads: 4 record groups per element (fixed-order partial sums, combined in

@@ -778,6 +778,55 @@ __global__ void k_finish_mse_packed(const float* od_part, const int64_t* goff, i
   dod[r] = -T * (2.f * (T - target[r]) * inv_n);
 }
 
+// Hierarchical step with coarse re-use: per ray, merge the S coarse depths and the NF new ones (coarse first on ties, as k_fine_depths), form the step
+// lengths of the merged list (last: 1e10) x ||d|| (render_volume_density, nerf/nerf_helpers.py:60-65), the optical depth, pixel = exp(-od), the MSE
+// gradient, and the finished dL/draw = dod dt sigma (1 - sigma) of every sample of both sets, written to the samples' stash rows
+// (gA[(r - ray0) spadA + i], gB[(r - ray0) spadB + k]).  One thread per ray, two walks over the S + NF depths.
+__global__ void k_hier_composite(const ChainArgs a, int64_t ray0, int64_t n_rays, const float* zf, int NF, const float* sig_c, const float* sig_f,
+                                 const float* target, float inv_n, float* pixel, float* gA, int spadA, float* gB, int spadB, float* z_all) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_rays) return;
+  const int64_t r = ray0 + i;
+  const int S = a.n_samples;
+  float ox, oy, oz, dx, dy, dz;
+  load_ray(a, (int)r, ox, oy, oz, dx, dy, dz);
+  const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+  const float* zc = a.depth_mode == 2 ? a.z + r * S : a.z;
+  const float* zn = zf + r * NF;
+  const float* sc = sig_c + r * S;
+  const float* sf = sig_f + r * NF;
+  float dod = 0.f;
+  for (int pass = 0; pass < 2; ++pass) {
+    int ic = 0, kf = 0;
+    float od = 0.f, pz = 0.f, psig = 0.f;
+    int pset = 0, pidx = 0;
+    for (int p = 0; p <= S + NF; ++p) {
+      float z = 0.f, sg = 0.f;
+      int set = 0, idx = 0;
+      if (p < S + NF) {
+        if (kf >= NF || (ic < S && zc[ic] <= zn[kf])) { z = zc[ic]; sg = sc[ic]; set = 0; idx = ic++; }
+        else { z = zn[kf]; sg = sf[kf]; set = 1; idx = kf++; }
+        if (pass == 1 && z_all) z_all[r * (S + NF) + p] = z;
+      }
+      if (p > 0) {      // the element before this one now knows its step: to this element, or 1e10 behind the last
+        const float dist = p < S + NF ? __fsub_rn(z, pz) : 1e10f;
+        const float dt = __fmul_rn(dist, nrm);
+        if (pass == 0) od += __fmul_rn(psig, dt);
+        else {
+          const float gv = dod * dt * (psig * (1.f - psig));
+          if (pset == 0) gA[i * spadA + pidx] = gv; else gB[i * spadB + pidx] = gv;
+        }
+      }
+      pz = z; psig = sg; pset = set; pidx = idx;
+    }
+    if (pass == 0) {
+      const float T = expf(-od);
+      pixel[r] = T;
+      dod = -T * (2.f * (T - target[r]) * inv_n);
+    }
+  }
+}
+
 // dL/d(optical depth) = -pixel * dL/dpixel
 __global__ void k_finish_bwd(const float* pixel, const float* dpix, int64_t n_rays, float* dod) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -934,8 +983,10 @@ __global__ void k_project_volume(const ChainArgs a, const VolArgs v) {
 #define AFX_MAX_FINE 512
 // tau != nullptr: the coarse pass's per-sample optical depths [R,S] instead of its weights: the weights of render_volume_density
 // (nerf_helpers.py:107-108), w_i = (1 - alpha_i + 1e-10) prod_{j<i} alpha_j with alpha = exp(-tau), are formed here, per ray, in order.
+// zf_out != nullptr: also the NF new depths alone, ascending [R,NF] (hierarchical step with coarse re-use: the second pass evaluates only these);
+// zout may then be null.
 __global__ void k_fine_depths(const float* zc, int z_per_ray, const float* wc, const float* tau, const float* u, int64_t n_rays,
-                              int S, int NF, float* zout) {
+                              int S, int NF, float* zout, float* zf_out = nullptr) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n_rays) return;
   const float* z = z_per_ray ? zc + r * S : zc;
@@ -977,6 +1028,9 @@ __global__ void k_fine_depths(const float* zc, int z_per_ray, const float* wc, c
     while (p > 0 && smp[p - 1] > v) { smp[p] = smp[p - 1]; --p; }
     smp[p] = v;
   }
+  if (zf_out)
+    for (int k2 = 0; k2 < NF; ++k2) zf_out[r * NF + k2] = smp[k2];
+  if (!zout) return;
   int i = 0, k = 0;
   float* o = zout + r * (S + NF);
   for (int p = 0; p < S + NF; ++p) {

@@ -288,6 +288,24 @@ class Engine:
                                                       _ptr(grad_flat), _ptr(ws), ws.numel(), self._stream(dev)), "afx_train_step_packed_mse")
         return pixel
 
+    def hier_train_step_mse(self, prepared, spec: RenderSpec, n_fine: int, u, target, inv_n: float, grad_flat, prec: str, want_z_all=True):
+        """afx_hier_train_step_mse: hierarchical step with coarse re-use; `spec` carries the rays and the COARSE depths (mode 'dense').
+        Returns (pixels [R], merged depths [R, S + n_fine] | None)."""
+        dev = prepared.device
+        target, u = _f32(target, "target", dev), _f32(u, "u", dev)
+        if target.numel() != spec.n_rays or tuple(u.shape) != (spec.n_rays, int(n_fine)):
+            raise ValueError("hier_train_step_mse: target [n_rays] and u [n_rays, n_fine] expected")
+        pixel = torch.empty(spec.n_rays, dtype=torch.float32, device=dev)
+        z_all = torch.empty(spec.n_rays, spec.n_samples + int(n_fine), dtype=torch.float32, device=dev) if want_z_all else None
+        a, keep = self._render_args(spec, dev, pixel)
+        full = int(self.lib.afx_hier_workspace_bytes(self.h, spec.n_rays, spec.n_samples, int(n_fine)))
+        ws = self._workspace(min(full, self.max_workspace_bytes), dev)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+        self._check(self.lib.afx_hier_train_step_mse(self.h, _lib.PREC[prec], _ptr(prepared), C.byref(a), int(n_fine), _ptr(u), _ptr(target),
+                                                    float(inv_n), _ptr(z_all), _ptr(grad_flat), self._stream(dev)), "afx_hier_train_step_mse")
+        del keep
+        return pixel, z_all
+
     def fused_step_available(self, n_samples: int, prec: str) -> bool:
         """afx_train_step_mse takes this ray length at this precision: rays that fit a 256-sample workgroup tile always (one
         kernel per chunk); any other length (300, 128 + 64, ...) as two half-kernels per chunk with the 8-bit-stash kernel, no

@@ -204,7 +204,7 @@ def train_step_packed_mse(model, ray_origins, ray_directions, packed, target: to
 
 def hierarchical_train_step_mse(model, ray_origins, ray_directions, depth_values, depth_samples_per_ray_fine: int,
                                 target: torch.Tensor, u: Optional[torch.Tensor] = None, n_global: Optional[int] = None,
-                                fine_model=None):
+                                fine_model=None, reuse_coarse: bool = True):
     """One hierarchical (coarse + fine) training pass on the fused kernels - the training step `fine_sampling`
     (nerf/nerf_helpers.py:178-195) belongs to, for the one-channel absorption model and an MSE loss on the fine render:
 
@@ -217,11 +217,33 @@ def hierarchical_train_step_mse(model, ray_origins, ray_directions, depth_values
         compositing, MSE gradient and backward without recomputing the forward (128 + 64 = 192 samples straddle the 256-sample
         workgroup tiles: the split-phase step of afx_train_step_mse at the f16s8 precision).
 
+    With ONE network (fine_model None, the reference's `fine_model or coarse_model`), f16s8 and no input encoding, the coarse depths are not evaluated
+    twice (`reuse_coarse`, default on): the coarse pass IS the forward half of the training kernel over the coarse depths (stash, masks, sigma, tau), a
+    second forward half evaluates only the N_f new depths, a per-ray kernel composites the merged list and hands every sample its finished dL/draw, and the
+    backward halves + weight gradients of both sets follow (afx_hier_train_step_mse) - a third less MLP work than coarse forward + fine step.
+
     Gradients are accumulated into `.grad` of the fine network as train_step_mse does.  Returns (loss, fine pixels, merged depths)."""
     _check_model(model)
     from . import engine as _engine
     n_rays = ray_origins.shape[0]
     z = depth_values
+    if (reuse_coarse and fine_model is None and model.precision == "f16s8" and model.engine.enc == "none"
+            and int(depth_samples_per_ray_fine) >= 2 and 3 <= int(z.shape[-1]) <= 512):
+        if u is None:
+            u = torch.rand(n_rays, int(depth_samples_per_ray_fine), device=model.flat_params.device)
+        n = _global_rays(n_rays, n_global, model.flat_params.device)
+        flat_grad = torch.zeros(model.engine.param_count, dtype=torch.float32, device=model.flat_params.device)
+        spec_c = RenderSpec(n_rays=n_rays, n_samples=int(z.shape[-1]), origins=ray_origins, dirs=ray_directions, mode="dense", z=z)
+        pixel, z_all = model.engine.hier_train_step_mse(model._prepared(), spec_c, int(depth_samples_per_ray_fine), u, target, 1.0 / n, flat_grad,
+                                                        model.precision)
+        if _grad_hook is not None:
+            _grad_hook(flat_grad)
+        for p, g in zip(model._fn_params(), model._fn_grads(flat_grad, None)):
+            if p.grad is None:
+                p.grad = g
+            else:
+                p.grad.add_(g)
+        return ((pixel - target) ** 2).sum() / n, pixel, z_all
     with torch.no_grad():
         spec_c = RenderSpec(n_rays=n_rays, n_samples=int(z.shape[-1]), origins=ray_origins, dirs=ray_directions, mode="dense", z=z)
         _, _, tau = model.engine.render_forward(model._prepared(), spec_c, model.precision, want_tau=True)
