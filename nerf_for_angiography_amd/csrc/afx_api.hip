@@ -876,7 +876,6 @@ extern "C" int afx_hier_train_step_mse(afx_ctx* c, int prec, const void* prepare
   const int S = r->n_samples, NF = n_fine;
   if (S < 3 || S > AFX_MAX_COARSE || NF < 1 || NF > AFX_MAX_FINE) return fail(AFX_E_INVALID, "afx_hier_train_step_mse: n_coarse in 3..%d, n_fine in 1..%d", AFX_MAX_COARSE, AFX_MAX_FINE);
   if (NF < 2) return fail(AFX_E_INVALID, "afx_hier_train_step_mse: n_fine must be >= 2");
-  if (int rc2 = check_dev(c, "afx_hier_train_step_mse")) return rc2;
   hipStream_t st = (hipStream_t)stream;
   const int F = c->d.width, N = c->d.n_hidden;
   const int64_t R = r->n_rays, spA = s_pad_of(S), spB = s_pad_of(NF);
@@ -888,11 +887,13 @@ extern "C" int afx_hier_train_step_mse(afx_ctx* c, int prec, const void* prepare
   int64_t nr = (R + 7) / 8 * 8;
   nr = std::min<int64_t>(nr, (int64_t)(plane_rows / (uint64_t)spA) / 8 * 8);
   while (nr >= 8 && fixed + hier_set_bytes(c, rup64((size_t)nr * spA, 256)) + hier_set_bytes(c, rup64((size_t)nr * spB, 256)) + 4096 > r->workspace_bytes) {
+    if (nr == 8) { nr = 0; break; }
     const int64_t n_chunks = (R + nr - 1) / nr + 1;          // next larger chunk count, equal chunks
-    nr = ((R + n_chunks - 1) / n_chunks + 7) / 8 * 8;
-    if (n_chunks > R) { nr = 0; break; }
+    const int64_t next = ((R + n_chunks - 1) / n_chunks + 7) / 8 * 8;
+    nr = next < nr ? next : nr - 8;                         // (strictly decreasing: the rounding to 8 rays can stall the chunk count)
   }
   if (nr < 8) return fail(AFX_E_WORKSPACE, "afx_hier_train_step_mse: workspace %zu too small for 8 rays per chunk", r->workspace_bytes);
+  if (int rc2 = check_dev(c, "afx_hier_train_step_mse")) return rc2;
   size_t off = 0;
   auto take = [&](size_t bytes) { char* p = ws + off; off += rup64(bytes, 256); return p; };
   float* sigA = (float*)take((size_t)R * S * 4);  float* tauA = (float*)take((size_t)R * S * 4);

@@ -100,6 +100,22 @@ def test_context_queries_and_validation_without_gpu():
     assert b"origins" in lib.afx_last_error()
     assert lib.afx_mlp_infer(h, 7, None, None, 4, None, 0, None) == -1
     lib.afx_destroy(h)
+    # hierarchical step with coarse re-use: its workspace query grows with the rays up to the 4 GiB-plane chunk, and a workspace that cannot
+    # hold 8 rays of both sample sets is refused (the chunk-sizing loop terminates: rays per chunk shrink in steps of at least 8)
+    d = _lib.ModelDesc(3, 0, 0, 256, 8)
+    assert lib.afx_create(C.byref(d), C.byref(h)) == 0
+    w9, w1k, w1m = (lib.afx_hier_workspace_bytes(h, n, 128, 64) for n in (9, 1000, 1 << 20))
+    assert 0 < w9 < w1k < w1m and lib.afx_hier_workspace_bytes(h, 1 << 22, 128, 64) - w1m < (1 << 22) * 4 * 400
+    args = _lib.RenderArgs()
+    args.n_rays, args.n_samples, args.ray_mode, args.depth_mode = 9, 35, _lib.RAYS_ARRAYS, _lib.DEPTH_SHARED_Z
+    args.origins = args.dirs = args.z = args.pixel = args.workspace = 4096      # (never dereferenced: validation and sizing come first)
+    fixed_only = lib.afx_hier_workspace_bytes(h, 9, 35, 7) // 3
+    for ws_bytes in (fixed_only, 1 << 20):
+        args.workspace_bytes = ws_bytes
+        rc = lib.afx_hier_train_step_mse(h, _lib.PREC["f16s8"], 4096, C.byref(args), 7, 4096, 4096, 1.0, None, 4096, None)
+        assert rc == -2 and b"workspace" in lib.afx_last_error(), (rc, lib.afx_last_error())
+    assert lib.afx_hier_train_step_mse(h, _lib.PREC["f16"], 4096, C.byref(args), 7, 4096, 4096, 1.0, None, 4096, None) == -1
+    lib.afx_destroy(h)
 
 
 def test_fused_path_refuses_cpu_tensors():
