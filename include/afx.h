@@ -96,7 +96,7 @@ enum afx_query_what {
   AFX_Q_K0 = 1,                /* encoded input width                               */
   AFX_Q_PREPARED_BYTES = 2,    /* bytes of the prepared-weights buffer (arg = prec) */
   AFX_Q_FWD_WORKSPACE = 3,     /* bytes needed by afx_render_forward  (arg0 = n_rays, arg1 = n_samples) */
-  AFX_Q_BWD_WORKSPACE_MIN = 4, /* smallest sensible backward workspace (arg0 = n_rays, 0 for afx_mlp_backward) */
+  AFX_Q_BWD_WORKSPACE_MIN = 4, /* smallest sensible backward workspace (arg0 = n_rays, 0 for afx_mlp_backward; arg1 = n_samples when the split training step is meant) */
   AFX_Q_BWD_WORKSPACE_FULL = 5 /* workspace that lets backward run in one chunk (arg0 = n_rays, arg1 = n_samples; afx_mlp_backward: arg0 = 0, arg1 = n_pts) */
 };
 int64_t afx_query(const afx_ctx* ctx, int what, int64_t arg0, int64_t arg1, int64_t arg2);
@@ -186,7 +186,7 @@ int afx_render_backward(afx_ctx* ctx, int prec, const void* prepared, const afx_
  * ceil(count_r / 32), int64 [R+1], the caller's cumsum), the tail of its last 32-sample group is dead padding (t_end <= t_start),
  * group_ray[g] = r - so a wavefront's 32 samples always belong to one ray.  afx_pack_groups builds ts_pad / te_pad / group_ray.
  * pixel[r] = prod exp(-sigmoid(raw) (t_e - t_s)) (1 for a ray without samples), L = inv_n sum_r (pixel_r - target_r)^2, grad_flat += dL/dparams.
- * AFX_PREC_F16S8 without an input encoding; the workspace (AFX_Q_BWD_WORKSPACE_FULL with arg0 = n_rays, arg1 = 32 * n_groups / n_rays rounded up,
+ * AFX_PREC_F16S8; the workspace (AFX_Q_BWD_WORKSPACE_FULL with arg0 = n_rays, arg1 = 32 * n_groups / n_rays rounded up,
  * or simply arg0 = 0, arg1 = 32 * n_groups plus n_rays + n_groups floats) must hold the whole list in one chunk. */
 int afx_pack_groups(const int64_t* offsets, const int64_t* group_offsets, int64_t n_rays, const float* t_starts, const float* t_ends,
                     float* ts_pad, float* te_pad, int32_t* group_ray, void* stream);
@@ -202,11 +202,11 @@ int afx_train_step_packed_mse(afx_ctx* ctx, int prec, const void* prepared, cons
  * grad_flat += dL/dparams; args->pixel receives the rendered pixels.  16-bit precisions only.
  * Rays whose padded sample count divides 256 lie inside one workgroup tile: ONE kernel per ray chunk.  Any other count (the
  * reference's own 300 samples per ray, nerf/run_nerf_acc.py:129; the 128 + 64 of the hierarchical pass) is taken by
- * AFX_PREC_F16S8 without an input encoding as the SAME work in two kernels per chunk - the forward half stashes H_l, the ReLU
+ * AFX_PREC_F16S8 (with or without an input encoding) as the SAME work in two kernels per chunk - the forward half stashes H_l, the ReLU
  * masks and g' = dt sigma (1 - sigma) per sample, a per-ray reduction forms pixel and dL/d(optical depth), the backward half
  * runs the input-gradient chain from the masks - so nothing is computed twice; the workspace must then also hold
  * n_rays * (1 + padded samples / 32) floats (AFX_Q_BWD_WORKSPACE_FULL with arg0 = n_rays, arg1 = n_samples includes them).
- * Other precisions / encodings return AFX_E_INVALID for such counts (render, then afx_render_backward). */
+ * Other precisions return AFX_E_INVALID for such counts (render, then afx_render_backward). */
 int afx_train_step_mse(afx_ctx* ctx, int prec, const void* prepared, const afx_render_args* args,
                        const float* target, float inv_n, float* grad_flat, void* stream);
 

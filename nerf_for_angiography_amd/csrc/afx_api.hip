@@ -292,7 +292,7 @@ extern "C" int64_t afx_query(const afx_ctx* c, int what, int64_t a0, int64_t a1,
     case AFX_Q_PREPARED_BYTES: return (int64_t)prep_layout(c, (int)a0).total;
     case AFX_Q_FWD_WORKSPACE: return (int64_t)rup64((size_t)a0 * (size_t)(s_pad_of((int)a1) / GROUP) * 4, 256);
     case AFX_Q_BWD_WORKSPACE_MIN: {
-      BwdLayout B = bwd_layout(c, (int)a2, a0, 128);
+      BwdLayout B = bwd_layout(c, (int)a2, a0, a1 > 0 ? s_pad_of((int)a1) / GROUP : 0);
       return (int64_t)(B.fixed_bytes + 32 * B.per_tile_bytes + 1024);
     }
     case AFX_Q_BWD_WORKSPACE_FULL: {
@@ -378,8 +378,10 @@ static int launch_chain_f(afx_ctx* c, int prec, bool bwd, const ChainArgs& a, si
     if (is_f16(prec)) return launch_chain_k(c, k_chain_bf16<F, false, false, false, 8, false, true, false, 0, 1>, which, a, lds, grid, st, 512);
     return launch_chain_k(c, k_chain_bf16<F, false, false, false, 8, false, false, false, 0, 1>, which, a, lds, grid, st, 512);
   }
-  if (phase == 1) return launch_chain_k(c, k_chain_bf16<F, false, false, true, 8, true, true, true, 1>, which, a, lds, grid, st, 512);
-  if (phase == 2) return launch_chain_k(c, k_chain_bf16<F, false, false, true, 8, true, true, true, 2>, which, a, lds, grid, st, 512);
+  if (phase == 1) return enc ? launch_chain_k(c, k_chain_bf16<F, false, true, true, 8, true, true, true, 1>, which, a, lds, grid, st, 512)
+                             : launch_chain_k(c, k_chain_bf16<F, false, false, true, 8, true, true, true, 1>, which, a, lds, grid, st, 512);
+  if (phase == 2) return enc ? launch_chain_k(c, k_chain_bf16<F, false, true, true, 8, true, true, true, 2>, which, a, lds, grid, st, 512)
+                             : launch_chain_k(c, k_chain_bf16<F, false, false, true, 8, true, true, true, 2>, which, a, lds, grid, st, 512);
   if (prec == AFX_PREC_F32)
     return bwd ? launch_chain_k(c, k_chain_f32<F, true>, which, a, lds, grid, st) : launch_chain_k(c, k_chain_f32<F, false>, which, a, lds, grid, st);
   if (prec == AFX_PREC_BF16X3 && !bwd)
@@ -597,7 +599,7 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
   const int k0ld = b16 ? 16 * nk0_of(c) : c->k0pad;     // row length of the encoded-input stash
   if (is_bf16(prec) && prec == AFX_PREC_F16S8 && a.mode == 1 && c->small_in_kernel)
     B.per_tile_bytes = per_tile_s8(c);     // 1 byte per stash element
-  if (split && !s8) return fail(AFX_E_INVALID, "split training step: needs the 8-bit-stash kernel (AFX_PREC_F16S8, no input encoding)");
+  if (split && !s8) return fail(AFX_E_INVALID, "split training step: needs the 8-bit-stash kernel (AFX_PREC_F16S8)");
   // a chunk of the split step holds whole rays: a multiple of lcm(s_pad, tile) / tile tiles
   int64_t ray_tiles = 1;
   if (split) { int64_t x = a.s_pad, y = TILE; while (y) { const int64_t t_ = x % y; x = y; y = t_; } ray_tiles = a.s_pad / x; }
@@ -775,9 +777,9 @@ extern "C" int afx_train_step_mse(afx_ctx* c, int prec, const void* prepared, co
   // hierarchical pass) the same work as two launches per chunk - forward half, per-ray reduction, backward half - for the
   // 8-bit-stash kernel; other precisions refuse (the Python layer renders, then calls afx_render_backward, which recomputes the forward)
   const bool split = 256 % s_pad != 0;
-  const bool can_split = prec == AFX_PREC_F16S8 && c->d.enc == AFX_ENC_NONE && c->small_in_kernel;
+  const bool can_split = prec == AFX_PREC_F16S8 && c->small_in_kernel;
   if (split && !can_split)
-    return fail(AFX_E_INVALID, "afx_train_step_mse: padded samples per ray (%d) must divide 256 at this precision / encoding", (int)s_pad);
+    return fail(AFX_E_INVALID, "afx_train_step_mse: padded samples per ray (%d) must divide 256 at this precision", (int)s_pad);
   ChainArgs a = {};
   fill_model(c, prec, true, prepared, a);
   fill_render(r, a);
@@ -813,8 +815,8 @@ extern "C" int afx_train_step_packed_mse(afx_ctx* c, int prec, const void* prepa
     return fail(AFX_E_INVALID, "afx_train_step_packed_mse: null argument");
   if (n_rays <= 0) return AFX_OK;
   if (n_groups < 0 || n_groups * 32 > ((int64_t)1 << 31) - 256) return fail(AFX_E_INVALID, "afx_train_step_packed_mse: n_groups out of range");
-  if (prec != AFX_PREC_F16S8 || c->d.enc != AFX_ENC_NONE || !c->small_in_kernel)
-    return fail(AFX_E_INVALID, "afx_train_step_packed_mse: AFX_PREC_F16S8 without an input encoding only");
+  if (prec != AFX_PREC_F16S8 || !c->small_in_kernel)
+    return fail(AFX_E_INVALID, "afx_train_step_packed_mse: AFX_PREC_F16S8 only");
   hipStream_t st = (hipStream_t)stream;
   const size_t dod_bytes = rup64((size_t)n_rays * 4, 256), od_bytes = rup64((size_t)std::max<int64_t>(n_groups, 1) * 4, 256);
   if (workspace_bytes < dod_bytes + od_bytes) return fail(AFX_E_WORKSPACE, "afx_train_step_packed_mse: workspace too small");

@@ -29,8 +29,8 @@
 #define AFX_CHAIN16_ACT_DEF(F, X3, NW, H16) \
   template __global__ void k_chain_bf16<F, X3, false, false, NW, false, H16, false, 0, 1>(const afx::ChainArgs);
 // split phases of the 8-bit-stash training kernel (PHASE 1 = forward half, 2 = backward half)
-#define AFX_CHAIN16_PHASES(X, F) X(F, 1) X(F, 2)
-#define AFX_CHAIN16_PH_DECL(F, PH) \
-  extern template __global__ void k_chain_bf16<F, false, false, true, 8, true, true, true, PH>(const afx::ChainArgs);
-#define AFX_CHAIN16_PH_DEF(F, PH) \
-  template __global__ void k_chain_bf16<F, false, false, true, 8, true, true, true, PH>(const afx::ChainArgs);
+#define AFX_CHAIN16_PHASES(X, F) X(F, false, 1) X(F, false, 2) X(F, true, 1) X(F, true, 2)
+#define AFX_CHAIN16_PH_DECL(F, ENC, PH) \
+  extern template __global__ void k_chain_bf16<F, false, ENC, true, 8, true, true, true, PH>(const afx::ChainArgs);
+#define AFX_CHAIN16_PH_DEF(F, ENC, PH) \
+  template __global__ void k_chain_bf16<F, false, ENC, true, 8, true, true, true, PH>(const afx::ChainArgs);

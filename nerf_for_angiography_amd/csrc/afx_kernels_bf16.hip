@@ -232,7 +232,7 @@ template <int K> __device__ __forceinline__ void lds_wait_frag(u32x4& r) {
 // the packed-ReLU steps.  Separate instantiations, so that the ReLU kernels stay exactly the code they were.
 template <int F, bool X3, bool ENC, bool BWD, int NW, bool SG = false, bool H16 = false, bool S8 = false, int PHASE = 0, int ACTV = 0>
 __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs a) {
-  static_assert(PHASE == 0 || (S8 && !ENC && PHASE <= 2), "split phases: the 8-bit-stash kernel without an input encoding");
+  static_assert(PHASE == 0 || (S8 && PHASE <= 2), "split phases: the 8-bit-stash kernel");
   static_assert(ACTV == 0 || (!BWD && !ENC), "tanh / sine: forward-only kernels without an input encoding");
   constexpr bool P1 = PHASE == 1, P2 = PHASE == 2;
   static_assert(!S8 || (SG && H16), "8-bit stash: f16 backward kernel with in-kernel small gradients");

@@ -308,10 +308,10 @@ class Engine:
 
     def fused_step_available(self, n_samples: int, prec: str) -> bool:
         """afx_train_step_mse takes this ray length at this precision: rays that fit a 256-sample workgroup tile always (one
-        kernel per chunk); any other length (300, 128 + 64, ...) as two half-kernels per chunk with the 8-bit-stash kernel, no
-        input encoding (include/afx.h)."""
+        kernel per chunk); any other length (300, 128 + 64, ...) as two half-kernels per chunk with the 8-bit-stash kernel
+        (include/afx.h)."""
         s_pad = (int(n_samples) + 31) // 32 * 32
-        return 256 % s_pad == 0 or (prec == "f16s8" and self.enc == "none" and os.environ.get("AFX_SMALL_IN_KERNEL", "1") != "0"
+        return 256 % s_pad == 0 or (prec == "f16s8" and os.environ.get("AFX_SMALL_IN_KERNEL", "1") != "0"
                                     and os.environ.get("AFX_NO_SPLIT", "0") == "0")      # (AFX_NO_SPLIT=1: A/B against the two-launch path)
 
     def train_step_mse(self, prepared, spec: RenderSpec, target, inv_n: float, grad_flat, prec: str):

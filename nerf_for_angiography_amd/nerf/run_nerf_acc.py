@@ -10,8 +10,8 @@ Three iteration bodies (--march): `dense` (default) is ONE fused launch per ray 
 MLP -> Beer-Lambert -> MSE -> backward; render + autograd with --precision f32); `grid` is the reference's own body,
 run_nerf_acc.py:284-306 - acc_update_n_step for both grids, acc_ray_marching with the occupancy grid (HIP march / visibility
 kernels, nerf/occupancy.py), then positions / get_predictions / acc_render_volume_density / mse_loss / backward as ONE fused pass
-over the march's packed samples (`train_step_packed_mse`; f16s8, no encoding); `grid_ops` is the same body call for call through
-the mirrored functions (also what `grid` does at the other precisions / with an encoding).
+over the march's packed samples (`train_step_packed_mse`; f16s8); `grid_ops` is the same body call for call through
+the mirrored functions (also what `grid` does at the other precisions).
 The training rays live on the GPU: one table (origins, directions, pixel, weight) built once, and every iteration's
 batch is drawn there (weighted sampling without replacement, `engine.sample_rays`); --host_sampler restores the
 reference's per-iteration pandas draw (`sample_pixel_rays`).
@@ -157,7 +157,7 @@ def main(argv=None):
     # the reference's second grid (:198,286): same updates at the vessel threshold; it only feeds the exported occupancy volumes (:362-367)
     vessel_acc_grid = OccupancyGrid(roi_aabb=scene_aabb, resolution=128, contraction_type=ContractionType.AABB, seed=args.seed + 1).to(device) \
         if args.march != 'dense' else None
-    packed_step = args.march == 'grid' and args.precision == 'f16s8' and args.pos_enc == 'none'      # else the operator sequence
+    packed_step = args.march == 'grid' and args.precision == 'f16s8'      # else the operator sequence
     batch_size = 131072
 
     os.makedirs(args.log_dir, exist_ok=True)

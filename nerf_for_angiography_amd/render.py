@@ -182,18 +182,22 @@ def train_step_packed_mse(model, ray_origins, ray_directions, packed, target: to
     mse_loss, backward (nerf/run_nerf_acc.py:289-306) - as ONE fused pass over the march's packed samples (engine.PackedGroups, from
     `occupancy.ray_marching(..., return_packed=True)` or `engine.pack_groups`): forward half, per-ray transmittance product, backward
     half, weight gradients; the MLP is evaluated once (the operator sequence evaluates it in the forward and again inside backward).
-    f16s8 precision, no input encoding.  Gradients are ACCUMULATED into `.grad` as loss.backward() would.  Returns (loss, pixels[n_rays]);
+    f16s8 precision (with or without an input encoding).  Gradients are ACCUMULATED into `.grad` as loss.backward() would.  Returns (loss, pixels[n_rays]);
     a ray without samples renders 1 (the empty product)."""
     _check_model(model)
-    if model.precision != "f16s8" or model.engine.enc != "none":
-        raise NotImplementedError("train_step_packed_mse: precision 'f16s8' without an input encoding (other configurations: the operator sequence "
+    if model.precision != "f16s8":
+        raise NotImplementedError("train_step_packed_mse: precision 'f16s8' (other precisions: the operator sequence "
                                   "get_predictions -> acc_render_volume_density -> mse_loss -> backward)")
     n = _global_rays(packed.n_rays, n_global, model.flat_params.device)
     flat_grad = torch.zeros(model.engine.param_count, dtype=torch.float32, device=model.flat_params.device)
-    pixel = model.engine.train_step_packed_mse(model._prepared(), ray_origins, ray_directions, packed, target, 1.0 / n, flat_grad, model.precision)
+    coef_grad = model._coef_grad_buffer()
+    with model.engine.encoding_grad(model.flat_params, coef_grad):
+        pixel = model.engine.train_step_packed_mse(model._prepared(), ray_origins, ray_directions, packed, target, 1.0 / n, flat_grad, model.precision)
     if _grad_hook is not None:
         _grad_hook(flat_grad)
-    for p, g in zip(model._fn_params(), model._fn_grads(flat_grad, None)):
+        if coef_grad is not None:
+            _grad_hook(coef_grad)
+    for p, g in zip(model._fn_params(), model._fn_grads(flat_grad, coef_grad)):
         if p.grad is None:
             p.grad = g
         else:

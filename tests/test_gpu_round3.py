@@ -558,8 +558,8 @@ def _packed_problem(n_rays, seed, empty_every=0):
     return o.to(DEV), d.to(DEV), tgt.to(DEV), ri, ts, te, packed
 
 
-@pytest.mark.parametrize("layers,width,n_rays", [(4, 128, 5625), (8, 256, 2000), (2, 64, 3)])
-def test_fused_packed_step_vs_operator_sequence_and_fp32(layers, width, n_rays):
+@pytest.mark.parametrize("layers,width,n_rays,enc", [(4, 128, 5625, "none"), (8, 256, 2000, "none"), (2, 64, 3, "none"), (4, 128, 5625, "barf")])
+def test_fused_packed_step_vs_operator_sequence_and_fp32(layers, width, n_rays, enc):
     """render.train_step_packed_mse - the reference's positions -> get_predictions -> acc_render_volume_density -> mse_loss -> backward
     (nerf/run_nerf_acc.py:289-306) as one fused pass over the grid march's packed samples - against that operator sequence through the mirrored
     functions at the exact-fp32 kernels (gradients) and at f16 (pixels bit-for-bit: same forward arithmetic); rays without samples render 1."""
@@ -571,7 +571,9 @@ def test_fused_packed_step_vs_operator_sequence_and_fp32(layers, width, n_rays):
     cnt = torch.bincount(ri.long(), minlength=n_rays)
     assert int((cnt == 0).sum()) > 0 or n_rays < 7
     torch.manual_seed(3)
-    m = make_model(layers, width, precision="f32")
+    m = make_model(layers, width, enc, precision="f32")
+    if enc == "barf":
+        m.update_barf_alpha(2.5, "pts")
     with torch.no_grad():
         m.output_linear[0].weight.mul_(4.0)
         m.output_linear[0].bias.fill_(-5.0)
@@ -692,3 +694,50 @@ def test_hierarchical_step_with_coarse_reuse(n_rays, sc, nf, layers, width, shar
     assert rel_l2(res[True][0].cpu().numpy(), out.rgb_map.detach().cpu().numpy()) < (5e-2 if few else 2e-3)
     e = float((res[True][2] - g32).norm() / g32.norm())
     assert e < (0.25 if few else TOL["f16s8"]["grad"]), e
+
+
+@pytest.mark.parametrize("enc", ["barf", "fourier"])
+def test_split_train_step_with_input_encoding(enc, monkeypatch):
+    """The split-phase step for ENCODED models (BARF / fourier, 33 encoded inputs; bf8 input stash, first layer and - fourier - the coefficient
+    contraction as rows of k_wgrad_s8) at the reference's 5 625 x 300: against the exact-fp32 kernels (Linear gradients) and, for the trainable
+    fourier coefficients, against the forward-launch + recomputing-backward path it replaces (AFX_NO_SPLIT=1)."""
+    from nerf_for_angiography_amd.render import render_rays, train_step_mse
+    from nerf_for_angiography_amd.engine import RenderSpec
+    o, d, tgt = _ref_iteration_problem(5625, seed=21)
+    o, d, tgt = o.to(DEV), d.to(DEV), tgt.to(DEV)
+    spec = RenderSpec(n_rays=5625, n_samples=300, origins=o, dirs=d, mode="acc", t_near=1400.0, t_far=1600.0)
+
+    def model(prec):
+        torch.manual_seed(4)
+        m = make_model(4, 128, enc, precision=prec)
+        if enc == "barf":
+            m.update_barf_alpha(2.5, "pts")
+        else:
+            with torch.no_grad():
+                m.fourier_coefficients.mul_(0.002)
+            m.fourier_coefficients.requires_grad_(prec != "f32")
+        with torch.no_grad():
+            m.output_linear[0].weight.mul_(4.0)
+            m.output_linear[0].bias.fill_(-5.0)
+        return m
+
+    m32 = model("f32")
+    out = render_rays(m32, o, d, 300, 1400.0, 1600.0, mode="acc")
+    torch.nn.functional.mse_loss(out.rgb_map, tgt).backward()
+    g32 = torch.cat([p.grad.reshape(-1) for p in m32._hip_params()]).double()
+    m = model("f16s8")
+    assert m.engine.fused_step_available(300, "f16s8")
+    _, pix = train_step_mse(m, spec, tgt)
+    g8 = torch.cat([p.grad.reshape(-1) for p in m._hip_params()]).double()
+    assert rel_l2(pix.cpu().numpy(), out.rgb_map.detach().cpu().numpy()) < 2e-3
+    assert float((g8 - g32).norm() / g32.norm()) < TOL["f16s8"]["grad"]
+    if enc == "fourier":
+        gc = m.fourier_coefficients.grad.double().clone()
+        assert bool(torch.isfinite(gc).all()) and float(gc.abs().max()) > 0
+        monkeypatch.setenv("AFX_NO_SPLIT", "1")
+        m2 = model("f16s8")
+        assert not m2.engine.fused_step_available(300, "f16s8")
+        _, pix2 = train_step_mse(m2, spec, tgt)
+        assert torch.equal(pix2, pix)
+        gc2 = m2.fourier_coefficients.grad.double()
+        assert float((gc - gc2).norm() / gc2.norm()) < 2 * TOL["f16s8"]["grad"]
