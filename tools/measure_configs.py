@@ -24,9 +24,13 @@ def model(prec="f16s8", enc="none"):
     m.engine.max_workspace_bytes = 128 << 30      # as bench.py: 288 GB of HBM per GPU, few large ray chunks
     return m
 
-def timeit(fn, warm=1, steps=3):
+def timeit(fn, warm=1, steps=3, min_time=1.0):
+    """Mean time of `fn` over at least `steps` calls and at least `min_time` seconds (a 12 ms step timed over 3 calls right after set-up reads 8 % high)."""
     for _ in range(warm): fn()
     torch.cuda.synchronize(); t0 = time.perf_counter()
+    fn(); torch.cuda.synchronize(); t1 = time.perf_counter() - t0
+    steps = max(steps, int(min_time / max(t1, 1e-6)))
+    t0 = time.perf_counter()
     for _ in range(steps): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / steps
 
@@ -61,7 +65,13 @@ m = model(); opt = torch.optim.Adam(m.parameters(), lr=1e-4)
 o, d, m44, _, _ = get_ray_values(20.0, 0.0, 0.0, np.array([0, 0, 1500.0]), W, W, 13.0 * W, dev)
 o, d = o.reshape(-1, 3).float().contiguous(), d.reshape(-1, 3).float().contiguous()
 tgt = torch.rand(W * W, device=dev); z = torch.linspace(1400.0, 1600.0, SC, device=dev)
-def step3():
+from nerf_for_angiography_amd.render import hierarchical_train_step_mse
+def step3_fused():      # the hierarchical step with the coarse depths evaluated once (afx_hier_train_step_mse)
+    opt.zero_grad(set_to_none=True); hierarchical_train_step_mse(m, o, d, z, NF, tgt); opt.step()
+tf = timeit(step3_fused)
+out["C3 512^2x(128 coarse + 64 new), coarse re-use"] = dict(ms_per_step=round(tf * 1e3, 2), ray_samples_per_s_reference_count=round(W * W * (SC + SC + NF) / tf / 1e6, 1))
+print("C3 fused", out["C3 512^2x(128 coarse + 64 new), coarse re-use"], flush=True)
+def step3():            # operator by operator: render with aux -> fine_sampling -> mse -> backward (recomputes the fine forward)
     opt.zero_grad(set_to_none=True)
     with torch.no_grad():
         coarse = render_rays(m, o, d, mode="dense", z=z, want_aux=True)
@@ -69,7 +79,7 @@ def step3():
     torch.nn.functional.mse_loss(rgb, tgt).backward(); opt.step()
 t = timeit(step3)
 m.engine.profile(True)
-t_again = timeit(step3, warm=0, steps=3)
+t_again = timeit(step3, warm=0, steps=3, min_time=0.0)
 kern = {k: round(m.engine.profile_read(k)[0] / 3, 2) for k in ("chain_fwd", "chain_bwd", "wgrad")}
 m.engine.profile(False)
 print("C3 again (profiled):", round(t_again * 1e3, 2), kern, "workspace at 0x%x, %.1f GiB" % (m.engine._ws.data_ptr(), m.engine._ws.numel() / 2**30), flush=True)
@@ -104,11 +114,11 @@ for layers, width in ((4, 128), (8, 256)):
         o, d, tgt, _ = sample_rays(tab_o, tab_d, tab_p, tab_w, R, seed=0, stream_id=step_no[0])
         spec = RenderSpec(n_rays=R, n_samples=S, origins=o, dirs=d, mode="acc", t_near=1400.0, t_far=1600.0)
         opt.zero_grad(set_to_none=True); train_step_mse(m, spec, tgt); opt.step()
-    t = timeit(it, warm=5, steps=50)
+    t = timeit(it, warm=5, steps=50, min_time=0.0)
     def sample_only():
         step_no[0] += 1
         sample_rays(tab_o, tab_d, tab_p, tab_w, R, seed=0, stream_id=step_no[0])
-    ts = timeit(sample_only, warm=2, steps=50)
+    ts = timeit(sample_only, warm=2, steps=50, min_time=0.0)
     out[f"reference training iteration 5625x300 {layers}x{width}"] = dict(ms_per_iter=round(t * 1e3, 3), iters_per_s=round(1 / t, 1),
                                                                           ray_samples_per_s=round(R * S / t / 1e6, 1),
                                                                           device_sampler_ms=round(ts * 1e3, 3))
