@@ -379,8 +379,17 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
     return cur;
   };
 
+  constexpr uint32_t MASKB = 2u * NT * NCG * NTH;      // mask bytes per layer (the LDS image, [((l*NT + t)*NCG + cg)*NTH + tid] u16)
   for (int tile = a.tile0 + blockIdx.x; tile < a.tile1; tile += gridDim.x) {
     STAMP(7);
+    if constexpr (P2) {
+      // masks of this tile: HBM -> LDS by LDS-DMA (1 KiB per wave instruction), behind a barrier that retires every reader of the previous tile's;
+      // issued FIRST, so that the ray / dL/draw loads of the tile prologue overlap its latency (waited for in front of the gradient seed)
+      asm volatile("s_barrier" ::: "memory");
+      const char* mg = a.masks + (size_t)(tile - a.tile0) * ((size_t)(N + 1) * MASKB);
+      for (uint32_t off = (uint32_t)wave * 1024u; off < (uint32_t)(N + 1) * MASKB; off += NW * 1024u)
+        __builtin_amdgcn_global_load_lds(GPTR(mg + off + lane * 16), LPTR((char*)mk16 + off), 16, 0, 0);
+    }
     int32_t n[NCG];
     uint32_t m[NCG], so[NCG];           // sample index, stash row, per-lane stash byte offset (chunk 0)
     Sample sp[NCG];
@@ -829,7 +838,6 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
         if (lane == 0) rec[3 * F + 6] = sg;
       }
     }
-    constexpr uint32_t MASKB = 2u * NT * NCG * NTH;      // mask bytes per layer (the LDS image, [((l*NT + t)*NCG + cg)*NTH + tid] u16)
     if constexpr (P1) {
       // the tile's ReLU masks, as they lie in LDS, go to HBM for the backward half: a cooperative 16-byte copy
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave's mask words are written
@@ -839,14 +847,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
       // (the next tile overwrites the LDS image only behind its first step barrier, which every wave reaches after issuing these stores,
       // i.e. after its LDS reads have returned)
     }
-    if constexpr (P2) {
-      // masks of this tile: HBM -> LDS by LDS-DMA (1 KiB per wave instruction), behind a barrier that retires every reader of the previous tile's
-      asm volatile("s_barrier" ::: "memory");
-      const char* mg = a.masks + (size_t)(tile - a.tile0) * ((size_t)(N + 1) * MASKB);
-      for (uint32_t off = (uint32_t)wave * 1024u; off < (uint32_t)(N + 1) * MASKB; off += NW * 1024u)
-        __builtin_amdgcn_global_load_lds(GPTR(mg + off + lane * 16), LPTR((char*)mk16 + off), 16, 0, 0);
-      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    }
+    if constexpr (P2) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // the tile's masks (requested at the top of the tile) are in LDS
     STAMP(9);      // output layer, compositing, output-layer sums, mask copy / load
     if constexpr (BWD && !P1) {
       // ---------------- input-gradient chain, 16-bit operands, fp32 accumulate.  bf16: dZ_l.  H16: J_l = dZ_l / g.
