@@ -265,7 +265,8 @@ static const int kSmallBlocks = 1024;  // blocks (and partial records) of k_smal
 // per-tile bytes of the 8-bit-stash mode: 1-byte H_l / dZ'_l planes, the input stash, per-sample words (group exponents / g'), and the
 // tile's ReLU-mask image (split phases): (N+1) layers x NT tiles x 512 lanes x 2 B
 static size_t per_tile_s8(const afx_ctx* c) {
-  return (size_t)256 * (2 * ((size_t)c->d.n_hidden + 1) * c->d.width + 4 * 16 * nk0_of(c) + 4 + 4) + ((size_t)c->d.n_hidden + 1) * c->nt * 1024;
+  return (size_t)256 * (2 * ((size_t)c->d.n_hidden + 1) * c->d.width + 4 * 16 * nk0_of(c) + 4 + 4) + ((size_t)c->d.n_hidden + 1) * c->nt * 1024
+         + (size_t)c->d.n_hidden * 32;      // H block scales: one dword per layer and 32-sample group
 }
 static BwdLayout bwd_layout(const afx_ctx* c, int prec, int64_t n_rays, int64_t groups_per_ray = 0) {
   const size_t F = c->d.width, N = c->d.n_hidden;
@@ -557,13 +558,21 @@ static int launch_wgrad16_t(afx_ctx* c, const WgradArgs& w, const ReduceArgs& rd
 template <int F>
 static int launch_wgrad8_t(afx_ctx* c, const WgradArgs& w, const ReduceArgs& rd, int N, hipStream_t st) {
   {
-    const size_t lds = (size_t)4 * (2 * (F / 16) * (64 * 16 + 128) + 64 * 4);      // 4-stage ring of (J + H image, dL/draw)
-    if (!c->attr_done.count((const void*)k_wgrad_s8<F>)) {
-      HIPCHK(hipFuncSetAttribute((const void*)k_wgrad_s8<F>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      c->attr_done.insert((const void*)k_wgrad_s8<F>);
-    }
+    const size_t lds = (size_t)4 * (2 * (F / 16) * (64 * 16 + 128) + 2 * 64 * 4);      // 4-stage ring of (J + H image, group exponents, H block scales)
+    constexpr bool H6 = AFX_H6_ON;      // hidden layers: B = the 6-bit H stash
+    for (const void* fn : {(const void*)k_wgrad_s8<F, H6>, (const void*)k_wgrad_s8<F, false>})
+      if (!c->attr_done.count(fn)) {
+        HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        c->attr_done.insert(fn);
+      }
     ProfScope ps(c, AFX_K_WGRAD, st);
-    hipLaunchKernelGGL(k_wgrad_s8<F>, dim3(w.n_splits, N + (w.enc16 ? 1 + (w.coef_cols > 0 ? 1 : 0) : 0)), dim3(512), lds, st, w);
+    const int extra = w.enc16 ? 1 + (w.coef_cols > 0 ? 1 : 0) : 0;      // the encoded first layer (and the fourier-coefficient contraction): B = the bf8 input stash
+    if (H6 && extra) {
+      hipLaunchKernelGGL((k_wgrad_s8<F, true>), dim3(w.n_splits, N), dim3(512), lds, st, w);
+      WgradArgs w1 = w;
+      w1.y0 = N;
+      hipLaunchKernelGGL((k_wgrad_s8<F, false>), dim3(w.n_splits, extra), dim3(512), lds, st, w1);
+    } else hipLaunchKernelGGL((k_wgrad_s8<F, H6>), dim3(w.n_splits, N + extra), dim3(512), lds, st, w);
   }
   hipLaunchKernelGGL(k_small_from_groups<F>, dim3(rd.n_small), dim3(F), 0, st, w);
   if (w.no_sw) hipLaunchKernelGGL(k_wout_stash8<F>, dim3(rd.n_small), dim3(2 * F), 0, st, w);      // output layer from the stash of H_N (same records)
@@ -647,15 +656,17 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
   const size_t rows = (size_t)chunk * TILE;
   float *stash_h[2], *stash_dz[2], *stash_e[2], *graw[2], *gpart[2];
   char* masks[2];
+  uint32_t* hexp[2];
   for (int bI = 0; bI < nbuf; ++bI) {
     stash_h[bI] = (float*)(ws + off); off += (size_t)(N + 1) * rows * F * esz;
     stash_dz[bI] = (float*)(ws + off); off += (size_t)(N + 1) * rows * F * esz;
     stash_e[bI] = (float*)(ws + off); off += rows * k0ld * 4;
     graw[bI] = (float*)(ws + off); off += rup64(rows * 4, 256);
-    gpart[bI] = nullptr; masks[bI] = nullptr;
+    gpart[bI] = nullptr; masks[bI] = nullptr; hexp[bI] = nullptr;
     if (s8) {
       gpart[bI] = (float*)(ws + off); off += rows * 4;
       masks[bI] = ws + off; off += (size_t)chunk * (N + 1) * c->nt * 1024;
+      hexp[bI] = (uint32_t*)(ws + off); off += (size_t)N * (rows / 32) * 4;
     }
   }
   a.stash_rows = (int64_t)rows;
@@ -678,7 +689,7 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
     if (nbuf == 2 && ci >= 2) HIPCHK(hipStreamWaitEvent(st, c->ev_wgrad[bI], 0));     // buffer bI has been consumed
     a.gmax = h16 ? gmax_words + 16 * bI : nullptr;
     if (h16) HIPCHK(hipMemsetAsync(a.gmax, 0, 4, st));
-    a.gpart = gpart[bI]; a.masks = masks[bI];
+    a.gpart = gpart[bI]; a.masks = masks[bI]; a.hexp = hexp[bI];
     int rc;
     if (split) {
       // forward half of the chunk, then the per-ray reduction over the chunk's (whole) rays, then the backward half
@@ -720,7 +731,7 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
     rps = (rps + 63) / 64 * 64;        // whole 32-/64-sample stages
     w.rows_per_split = (int)rps;
     w.partial = partial; w.partial2 = partial2; w.partial_s = partial_s; w.debug = a.debug; w.small_groups = sg ? 1 : 0;
-    w.gmax = a.gmax; w.stash_esz = (int)esz; w.gexp = a.gexp; w.enc16 = enc16 ? 1 : 0; w.coef_cols = a.coef_cols;
+    w.gmax = a.gmax; w.stash_esz = (int)esz; w.gexp = a.gexp; w.hexp = a.hexp; w.enc16 = enc16 ? 1 : 0; w.coef_cols = a.coef_cols;
     w.dod = split ? a.dod : nullptr; w.gpr = a.s_pad / GROUP; w.group0 = t0 * (TILE / GROUP); w.group_ray = goff ? a.group_ray : nullptr;
     w.n_groups_valid = goff ? a.n_total / GROUP : n_rays * (int64_t)(a.s_pad / GROUP);
     ReduceArgs rd = {};
@@ -844,7 +855,8 @@ extern "C" int afx_train_step_packed_mse(afx_ctx* c, int prec, const void* prepa
 // dL/draw per row, the tiles' mask images, the group records.
 static size_t hier_set_bytes(const afx_ctx* c, size_t rows) {
   const size_t F = c->d.width, N = c->d.n_hidden, tiles = rows / 256;
-  return 2 * (N + 1) * rows * F + rup64(rows * 4, 256) + rows * 4 + tiles * (N + 1) * c->nt * 1024 + rup64((rows / 32) * (3 * F + 8) * 4, 256);
+  return 2 * (N + 1) * rows * F + rup64(rows * 4, 256) + rows * 4 + tiles * (N + 1) * c->nt * 1024 + rup64((rows / 32) * (3 * F + 8) * 4, 256) +
+         rup64(N * (rows / 32) * 4, 256);      // + H block scales
 }
 static size_t hier_fixed_bytes(const afx_ctx* c, int64_t n_rays, int S, int NF) {
   const size_t F = c->d.width, N = c->d.n_hidden;
@@ -905,13 +917,14 @@ extern "C" int afx_hier_train_step_mse(afx_ctx* c, int prec, const void* prepare
   float* partial2 = (float*)take((size_t)(N + 2) * kSplits * (F + 4) * 4);
   float* partial_s = (float*)take((size_t)kSmallBlocks * (F * 16 + 2 * F + 4) * 4);
   uint32_t* gmax = (uint32_t*)take(256);
-  struct SetBuf { char *stash_h, *stash_dz, *gexp, *masks; float *gpart, *records; size_t rows; };
+  struct SetBuf { char *stash_h, *stash_dz, *gexp, *masks, *hexp; float *gpart, *records; size_t rows; };
   auto carve = [&](size_t rows) {
     SetBuf b; b.rows = rows;
     b.stash_h = take((size_t)(N + 1) * rows * F); b.stash_dz = take((size_t)(N + 1) * rows * F);
     b.gexp = take(rows * 4); b.gpart = (float*)take(rows * 4);
     b.masks = take((rows / 256) * (size_t)(N + 1) * c->nt * 1024);
     b.records = (float*)take((rows / 32) * (size_t)(3 * F + 8) * 4);
+    b.hexp = take((size_t)N * (rows / 32) * 4);
     return b;
   };
   const SetBuf A = carve(rup64((size_t)nr * spA, 256)), B = carve(rup64((size_t)nr * spB, 256));
@@ -926,7 +939,7 @@ extern "C" int afx_hier_train_step_mse(afx_ctx* c, int prec, const void* prepare
     ChainArgs a = src;
     a.tile0 = (int)(r0 * sp / 256); a.tile1 = (int)((r1 * sp + 255) / 256);
     a.stash_h = (float*)b.stash_h; a.stash_dz = (float*)b.stash_dz; a.stash_e = nullptr; a.graw = (float*)b.gexp; a.gexp = (int32_t*)b.gexp;
-    a.gpart = b.gpart; a.masks = b.masks; a.small_part = b.records; a.stash_rows = (int64_t)b.rows;
+    a.gpart = b.gpart; a.masks = b.masks; a.small_part = b.records; a.stash_rows = (int64_t)b.rows; a.hexp = (uint32_t*)b.hexp;
     return a;
   };
   ChainArgs argsA = base;                     // the coarse set: the caller's depths
@@ -946,7 +959,7 @@ extern "C" int afx_hier_train_step_mse(afx_ctx* c, int prec, const void* prepare
     w.n_splits = splits;
     w.rows_per_split = (int)(((w.rows + splits - 1) / splits + 63) / 64 * 64);
     w.partial = partial; w.partial2 = partial2; w.partial_s = partial_s; w.debug = 0; w.small_groups = 1;
-    w.gmax = gmax; w.stash_esz = 1; w.gexp = a.gexp; w.enc16 = 0; w.coef_cols = 0;
+    w.gmax = gmax; w.stash_esz = 1; w.gexp = a.gexp; w.hexp = a.hexp; w.enc16 = 0; w.coef_cols = 0;
     w.dod = nullptr; w.gpr = 1; w.group0 = 0; w.n_groups_valid = 0; w.group_ray = nullptr;
     w.records = b.records; w.no_sw = 1; w.gfull = b.gpart;
     ReduceArgs rd = {};

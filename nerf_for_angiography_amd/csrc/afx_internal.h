@@ -81,6 +81,7 @@ struct ChainArgs {
   uint32_t* gmax;           // f16 mode: bit pattern of max |dL/draw| over the chunk (integer atomicMax; zeroed per chunk)
   int32_t stash8;           // f16 mode: 8-bit (bf8) stash of H_l and dZ'_l
   int32_t* gexp;            // 8-bit stash: power-of-two exponent of each 32-sample group's largest |dL/draw| [rows/32]
+  uint32_t* hexp;           // 6-bit H stash: [N][rows/32] the E8M0 block scales of H_l, one byte per 64-feature tile pair
   int32_t coef_cols;        // 3*n_freq when the fourier coefficients train (the chain kernel then also stashes d(enc)/d(coef)/(2 pi)), else 0
   // hierarchical step with coarse re-use (afx_hier_train_step_mse): PHASE 1 runs before the samples' final step lengths are known (the fine depths
   // depend on this very pass): it stashes H_N as well (the output layer's gradient is contracted from the stash later) and forms no g' sums;
@@ -114,6 +115,8 @@ struct WgradArgs {
   const uint32_t* gmax;     // f16 mode: the chunk's max |dL/draw| (scale of the contraction, wgrad_scale_exp)
   int32_t stash_esz;        // bytes per stash element (4 f32, 2 bf16/f16, 1 bf8)
   const int32_t* gexp;      // 8-bit stash: group exponents (block scales of the MX contraction)
+  int y0;                   // k_wgrad_s8: grid row of the launch's first block row (hidden layers 0..N-1, then the encoded first layer's rows)
+  const uint32_t* hexp;     // 6-bit H stash: [N][stride_rows/32] E8M0 bytes of H_l's tile pairs (B operand's block scales)
   int32_t enc16;            // 16-bit kernels with an encoding: stash_e is the 16-bit chunk-major input stash; k_wgrad_bf16 contracts layer 0 on
                             // the matrix pipe (blockIdx.y = n_hidden) and, with coef_cols > 0, d(enc)/d(coef) as well (blockIdx.y = n_hidden + 1)
   int32_t coef_cols;        // 3*n_freq when the fourier coefficients train, else 0

@@ -85,6 +85,45 @@ template <int F> __device__ __forceinline__ uint32_t stash_off(uint32_t r, int c
 template <int F> __device__ __forceinline__ uint32_t stash_off8(uint32_t r, int ch16) {
   return ((((r >> 5) * (F / 16) + ch16) << 5) + (r & 31)) << 4;
 }
+#ifndef AFX_GAPS      // (the MFMA-gap schedule of the 8-bit-stash backward kernel, described below)
+#define AFX_GAPS 0
+#endif
+#define AFX_GAPS_ON AFX_GAPS
+// H6 (6-bit H stash; -DAFX_H6=1, build.py --variant=h6 - built, tested, NOT the default: on the 512^2 x 128 step it takes 1 ms off
+// k_wgrad_s8 and puts 1.6 ms on the chain kernel): the hidden
+// activations H_l (l < N), the B operand of the weight-gradient contraction, are stashed as bf6 (e3m2: the 2 mantissa bits of bf8, 3 exponent
+// bits) with ONE power-of-two scale per (32-sample group, 64-feature tile pair) - the E8M0 block scale the matrix instruction takes for B.
+// A wave owns exactly that block (32 sample columns x the 64 features of two consecutive tiles), so the scale is a wave-wide max: 15
+// v_pk_max_u16 on the packed non-negative f16 patterns, 6 DPP steps, one v_readlane; the largest value lands in [8, 16) of e3m2's [1/16, 28].
+// v_cvt_scalef32_pk32_bf6_f16 packs a lane's 32 values of the pair into 6 dwords, element i in bit field 6 i (tools/micro/fp6_probe.hip):
+// dwords 0-2 = the lane's 16 values of tile t = 12-byte unit 2t + h, dwords 3-5 = unit 2(t+1) + h; positions inside a unit as in the bf8
+// layout (fperm8).  Layout [row>>5][unit][row&31][12 B]: a wave's dwordx3 store is one contiguous 768-byte run.  3/4 of the bf8 bytes; the
+// plane stride stays rows x F.  The four (F = 256) E8M0 bytes of a group and layer travel as one dword, a.hexp[l][group].
+#ifndef AFX_H6
+#define AFX_H6 0
+#endif
+#define AFX_H6_ON (AFX_H6 && !AFX_GAPS_ON)
+typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+typedef unsigned u32x6 __attribute__((ext_vector_type(6)));
+typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x32_t __attribute__((ext_vector_type(32)));
+template <int F> __device__ __forceinline__ uint32_t stash_off6(uint32_t r, int unit) {
+  return ((((r >> 5) * (F / 16) + unit) << 5) + (r & 31)) * 12u;
+}
+__device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b) {      // (builtin, not asm: hipcc pads asm with s_nop and cannot interleave it)
+  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
+}
+// max over the wave of a non-negative value; the result is wave-uniform (an SGPR)
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));      // row_shr:1
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));      // row_shr:2
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));      // row_shr:4
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));      // row_shr:8: lane 15 of a row holds the row's max
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));      // row_bcast:15 into rows 1 and 3
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));      // row_bcast:31 into rows 2 and 3
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
 // 8 packed f16 pairs (16 values, stash order) -> 16 bf8 bytes; value / scale is what is stored
 __device__ __forceinline__ u32x4 to_bf8x16(u32x4 a, u32x4 b, float scale) {
   u32x4 r;
@@ -136,9 +175,6 @@ template <int... I, class Fn> __device__ __forceinline__ void static_for_impl(st
 template <int N_, class Fn> __device__ __forceinline__ void static_for(Fn&& f) { static_for_impl(std::make_integer_sequence<int, N_>{}, f); }
 // AFX_GAPS=1 (build.py --variant=gaps): the MFMA-gap schedule of the 8-bit-stash backward kernel, kept for A/B.  It measured
 // 3 ms SLOWER per step than the plain order, with real and with all-zero operands, so the default is off.
-#ifndef AFX_GAPS
-#define AFX_GAPS 0
-#endif
 // stash position -> feature for the 8-bit layout (a permutation inside each block of 32)
 __device__ __forceinline__ int fperm8(int p) {
   const int hh = (p >> 4) & 1, s2 = (p >> 3) & 1, j = p & 7;
@@ -334,6 +370,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
   // GAPS (8-bit stash kernel): stash stores move between tiles, so the wave counts them; a step that issued fewer than SPS
   // behind its request is followed by a full wait (wave-uniform scalar counter).
   constexpr bool GAPS = S8 && AFX_GAPS && PHASE == 0;
+  constexpr bool H6 = S8 && AFX_H6_ON;      // bf6 H stash (the gap-schedule A/B build keeps the bf8 one)
+  static_assert(!H6 || (NCG == 1 && NT % 2 == 0 && TPS % 2 == 0), "6-bit H stash: a wave owns one 32-sample group and whole tile pairs per step");
   constexpr int IPG = 16 / (2 * NT);     // work items per MFMA gap (GAPS)
   int nstores = 0;
   // GAPS: a hidden step's request is issued piece by piece in the first MFMA gaps of the step's first tile (defer = true):
@@ -392,6 +430,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
     }
     int32_t n[NCG];
     uint32_t m[NCG], so[NCG];           // sample index, stash row, per-lane stash byte offset (chunk 0)
+    uint32_t so6 = 0, hx = 0;           // H6: byte offset of unit h in the 6-bit layout; the layer's E8M0 bytes so far
     Sample sp[NCG];
     u32x4 ehi[NCG][NK0], elo[NCG][NK0];
 #pragma unroll
@@ -399,6 +438,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
       n[cg] = tile * TS + wave * (32 * NCG) + cg * 32 + col;
       m[cg] = (uint32_t)(tile - a.tile0) * TS + wave * (32 * NCG) + cg * 32 + col;
       so[cg] = S8 ? stash_off8<F>(m[cg], hh) : stash_off<F>(m[cg], hh);
+      if constexpr (H6) so6 = stash_off6<F>(m[cg], hh);
       sp[cg] = make_sample(a, n[cg]);
       // first-layer B fragments: element j of k-step q is encoded input k = 16q + 8*(lane>>5) + j
 #pragma unroll
@@ -511,7 +551,35 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
             stash_store((char*)a.stash_h + (size_t)l * a.stash_rows * (F * 2) + (so[cg] + (uint32_t)(4 * t + 2 * s) * 512u), nf[s]);
           }
         }
-        if constexpr (S8) {
+        if constexpr (H6) {
+          if (l != N) {
+            if (t & 1) {      // tiles t-1 and t: one scale, one conversion, two 12-byte stores per lane (as many stores per step as the bf8 stash: vmcnt protocol unchanged)
+              const u32x4* pr = nf - 2;
+              unsigned mx = pk_max_u16(pk_max_u16(pk_max_u16(pr[0][0], pr[0][1]), pk_max_u16(pr[0][2], pr[0][3])),
+                                       pk_max_u16(pk_max_u16(pr[1][0], pr[1][1]), pk_max_u16(pr[1][2], pr[1][3])));
+              mx = pk_max_u16(mx, pk_max_u16(pk_max_u16(pk_max_u16(pr[2][0], pr[2][1]), pk_max_u16(pr[2][2], pr[2][3])),
+                                             pk_max_u16(pk_max_u16(pr[3][0], pr[3][1]), pk_max_u16(pr[3][2], pr[3][3]))));
+#ifdef AFX_H6_CONST      // measurement build only (build.py --variant=h6c): no max, scale 1 - the cost of the scale computation by difference
+              const unsigned e8 = 127u + (mx & 0u);
+#else
+              const unsigned e8 = 109u + (wave_max_u32(max(mx & 0xffffu, mx >> 16)) >> 10);      // E8M0 of 2^(exponent of the max - 3)
+#endif
+              hx |= e8 << (8 * (t >> 1));
+              const u32x16 v16 = {pr[0][0], pr[0][1], pr[0][2], pr[0][3], pr[1][0], pr[1][1], pr[1][2], pr[1][3],
+                                  pr[2][0], pr[2][1], pr[2][2], pr[2][3], pr[3][0], pr[3][1], pr[3][2], pr[3][3]};
+              const u32x6 r6 = __builtin_amdgcn_cvt_scalef32_pk32_bf6_f16(__builtin_bit_cast(f16x32_t, v16), __uint_as_float(e8 << 23));
+              char* hp = (char*)a.stash_h + (size_t)l * a.stash_rows * F + (so6 + (uint32_t)(2 * (t - 1)) * 384u);
+              __builtin_nontemporal_store((u32x3){r6[0], r6[1], r6[2]}, (u32x3*)hp);
+              __builtin_nontemporal_store((u32x3){r6[3], r6[4], r6[5]}, (u32x3*)(hp + 768));
+              if (t == NT - 1) {
+                if (lane == 0) a.hexp[(size_t)l * (a.stash_rows >> 5) + (m[cg] >> 5)] = hx;
+                hx = 0;
+              }
+            }
+          } else if (P1 && a.defer_out) {     // H_N for k_wout_stash8 (hierarchical step): bf8, as before
+            stash_store((char*)a.stash_h + (size_t)l * a.stash_rows * F + (so[cg] + (uint32_t)(2 * t) * 512u), to_bf8x16(nf[0], nf[1], 1.0f));
+          }
+        } else if constexpr (S8) {
           if ((l != N || (P1 && a.defer_out)) && !(GAPS && (l >= 1 || t == NT - 1))) {     // one 16-byte store per tile: chunk 2t + h of the 8-bit layout
             ++nstores;
             stash_store((char*)a.stash_h + (size_t)l * a.stash_rows * F + (so[cg] + (uint32_t)(2 * t) * 512u), to_bf8x16(nf[0], nf[1], 1.0f));
@@ -1232,8 +1300,19 @@ __global__ void __launch_bounds__(512) k_wgrad_bf16(const WgradArgs a) {
 // Every LDS read of the loop is inline asm: hipcc orders a plain LDS load (and the ds_read_tr builtins) behind ALL
 // outstanding LDS-DMA with an s_waitcnt vmcnt(0), which would put the whole DMA round trip back in front of every stage.
 // ---------------------------------------------------------------------------------------
+// H6 (6-bit H stash, see stash_off6): B = H_{l-1} arrives as bf6.  Its stage pieces are 12-byte LDS-DMA instructions
+// (global_load_lds_dwordx3 writes lane l's 12 bytes at base + 16 l: the LDS image keeps the bf8 image's geometry, rows at a 16-byte stride,
+// which is what ds_read_b96_tr_b6 wants - tools/micro/fp6_probe2.hip), two transposed reads per column tile deliver a lane's 32 samples x 1
+// position (lane i of a 16-lane group supplies row i and receives field i of the 16 rows), and the instruction takes A = bf8, B = bf6
+// (cbsz 1, blgp 3).  K mapping of the mixed formats (tools/micro/fp6_probe.hip): B's lane half h holds K = 32 h + e in field e, A's
+// K = 32 (k >> 4) + 16 h + (k & 15) at byte k as before; B's block scale for K-block b comes from the lanes of half b like A's.  The E8M0
+// byte of this wave's column tile pair is picked out of the group's dword.
 typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x3 __attribute__((ext_vector_type(3)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void lds_tr6(i32x3& dst, uint32_t addr, int imm) {
+  asm volatile("ds_read_b96_tr_b6 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm) : "memory");
+}
 __device__ __forceinline__ void lds_tr8(i32x2& dst, uint32_t addr, int imm) {
   asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm) : "memory");
 }
@@ -1241,7 +1320,7 @@ __device__ __forceinline__ void lds_rd32(int& dst, uint32_t addr, int imm) {
   asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm) : "memory");
 }
 
-template <int F>
+template <int F, bool B6>      // B6: B = the 6-bit H stash (hidden layers); otherwise bf8 (the encoded inputs' rows, and every row of the h8 A/B build)
 __global__ void __launch_bounds__(512) k_wgrad_s8(const WgradArgs a) {
   constexpr int NT = F / 32;
   constexpr int TR = NT >= 2 ? NT / 2 : 1, WR = NT / TR;
@@ -1253,6 +1332,9 @@ __global__ void __launch_bounds__(512) k_wgrad_s8(const WgradArgs a) {
   constexpr int NS = 4;                      // ring depth
   constexpr int GOFF = NS * 2 * IMG;         // per stage: the two group exponents, replicated over 64 dwords
   constexpr int PER = 2 * ((NCH + 7) / 8);   // LDS-DMA instructions per wave and stage (waves beyond NCH: none, their waits are no-ops)
+  constexpr bool H6 = B6;
+  constexpr int XW0 = H6 ? 2 : 1;            // wave 0's extra pieces per stage: the group exponents (and H's block scales)
+  constexpr int HOFF = GOFF + NS * KB * 4;   // per stage: the two groups' H block-scale dwords, replicated like the exponents
   static_assert(2 * (NT - 1) * CS + 3 * 128 + 1151 < 65536 && IMG < 65536, "ds offset immediates are 16 bits");
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, col = lane & 31, hh = lane >> 5;
@@ -1260,13 +1342,14 @@ __global__ void __launch_bounds__(512) k_wgrad_s8(const WgradArgs a) {
   // blockIdx.y < N: hidden layer blockIdx.y + 1.  enc16 (encoded inputs): blockIdx.y = N is the FIRST layer - A = dZ'_0, B = the 8-bit stash
   // of the 64 input columns (4 chunk columns, natural column order) - and blockIdx.y = N + 1 the fourier-coefficient contraction
   // (B = d(enc)/d(coef)/(2 pi)); both produce the two left-most column tiles only.
-  const int first = (int)blockIdx.y - a.n_hidden;           // < 0: hidden layer
-  const int layer = first < 0 ? (int)blockIdx.y + 1 : 0, split = blockIdx.x;
+  const int first = (int)blockIdx.y + a.y0 - a.n_hidden;    // < 0: hidden layer (a.y0: first grid row of this launch)
+  const int layer = first < 0 ? (int)blockIdx.y + a.y0 + 1 : 0, split = blockIdx.x;
   const int slot = first <= 0 ? layer : a.n_hidden + 1;     // partial slot
   const int E = wgrad_scale_exp(a.gmax);
   const char* A = (const char*)a.stash_dz + (size_t)layer * a.stride_rows * F;
   const char* B = first < 0 ? (const char*)a.stash_h + (size_t)(layer - 1) * a.stride_rows * F
                             : (const char*)a.stash_e + (size_t)first * a.stride_rows * 64;
+  const uint32_t* hexp = a.hexp + (size_t)(first < 0 ? layer - 1 : 0) * (size_t)(a.stride_rows >> 5);      // (first layer: read, not used)
   int64_t r0 = (int64_t)split * a.rows_per_split;
   int64_t r1 = r0 + a.rows_per_split;
   if (r1 > a.rows) r1 = a.rows;
@@ -1290,14 +1373,18 @@ __global__ void __launch_bounds__(512) k_wgrad_s8(const WgradArgs a) {
     for (int c = wave; c < NCH; c += 8) {
       const size_t src = ((((size_t)(g0 + hh) * NCH + c) << 5) + col) << 4;
       __builtin_amdgcn_global_load_lds(GPTR(A + src), LPTR(dA + c * CS), 16, 0, 0);
-      if (first < 0) __builtin_amdgcn_global_load_lds(GPTR(B + src), LPTR(dB + c * CS), 16, 0, 0);
+      if constexpr (B6) __builtin_amdgcn_global_load_lds(GPTR(B + (src >> 4) * 12), LPTR(dB + c * CS), 12, 0, 0);
+      else if (first < 0) __builtin_amdgcn_global_load_lds(GPTR(B + src), LPTR(dB + c * CS), 16, 0, 0);
       else {      // input stash: 4 chunk columns; every wave still issues one B piece per A piece (column c mod 4, identical data where
                   // two waves meet), so that the counted vmcnt below holds for every grid row
         const size_t srcb = ((((size_t)(g0 + hh) * 4 + (c & 3)) << 5) + col) << 4;
         __builtin_amdgcn_global_load_lds(GPTR(B + srcb), LPTR(dB + (c & 3) * CS), 16, 0, 0);
       }
     }
-    if (wave == 0) __builtin_amdgcn_global_load_lds(GPTR(a.gexp + g0 + hh), LPTR(lds + GOFF + buf * (KB * 4)), 4, 0, 0);
+    if (wave == 0) {
+      __builtin_amdgcn_global_load_lds(GPTR(a.gexp + g0 + hh), LPTR(lds + GOFF + buf * (KB * 4)), 4, 0, 0);
+      if constexpr (H6) __builtin_amdgcn_global_load_lds(GPTR(hexp + g0 + hh), LPTR(lds + HOFF + buf * (KB * 4)), 4, 0, 0);
+    }
   };
   const int g4 = lane >> 4, li = lane & 15;
   // lane 2q+p of a 16-lane group: row q of an 8-row block, bytes 8p..8p+7 of chunk 2T + (g4&1); read r (registers 2r, 2r+1)
@@ -1305,6 +1392,8 @@ __global__ void __launch_bounds__(512) k_wgrad_s8(const WgradArgs a) {
   const uint32_t lbase = (uint32_t)(uintptr_t)LPTR(lds);
   const uint32_t troff = (uint32_t)((g4 & 1) * CS + (16 * (g4 >> 1) + (li >> 1)) * 16 + 8 * (li & 1));
   const uint32_t offA = troff + (uint32_t)(2 * wr * TR * CS), offB = troff + (uint32_t)(IMG + 2 * wc * TC * CS);
+  // bf6: lane i of 16-lane group g4 supplies row 32 (g4 >> 1) + i (+ 16 for the second read) of unit 2T + (g4 & 1)
+  const uint32_t offB6 = (uint32_t)(IMG + 2 * wc * TC * CS + (g4 & 1) * CS + (32 * (g4 >> 1) + li) * 16);
 
 #pragma unroll
   for (int i = 0; i < NS - 1; ++i)
@@ -1315,7 +1404,7 @@ __global__ void __launch_bounds__(512) k_wgrad_s8(const WgradArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
     if (st + NS - 2 < nst) {
-      if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NS - 2) * (PER + 1)) : "memory");
+      if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NS - 2) * (PER + XW0)) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NS - 2) * PER) : "memory");
     } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the last stages: fewer younger ones to count on
 #endif
@@ -1326,30 +1415,65 @@ __global__ void __launch_bounds__(512) k_wgrad_s8(const WgradArgs a) {
     if (active) {
       const uint32_t sbase = lbase + (uint32_t)((st % NS) * 2 * IMG);
       i32x2 ax[TR][4], bx[TC][4];
-      int eg;
+      i32x3 b6[TC][2];
+      int eg, hx = 0;
+      constexpr bool six = B6;
 #pragma unroll
       for (int i = 0; i < TR; ++i)
 #pragma unroll
         for (int q = 0; q < 4; ++q) lds_tr8(ax[i][q], sbase + offA, 2 * i * CS + (q >> 1) * 512 + (q & 1) * 128);
+      if constexpr (six) {
 #pragma unroll
-      for (int j = 0; j < TC; ++j)
+        for (int j = 0; j < TC; ++j)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) lds_tr8(bx[j][q], sbase + offB, 2 * j * CS + (q >> 1) * 512 + (q & 1) * 128);
+          for (int q = 0; q < 2; ++q) lds_tr6(b6[j][q], sbase + offB6, 2 * j * CS + q * 256);
+        lds_rd32(hx, lbase + (uint32_t)(HOFF + (st % NS) * (KB * 4)) + (uint32_t)lane * 4u, 0);
+      } else {
+#pragma unroll
+        for (int j = 0; j < TC; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) lds_tr8(bx[j][q], sbase + offB, 2 * j * CS + (q >> 1) * 512 + (q & 1) * 128);
+      }
       lds_rd32(eg, lbase + (uint32_t)(GOFF + (st % NS) * (KB * 4)) + (uint32_t)lane * 4u, 0);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // the reads are inline asm, so the compiler does not know their results are in flight: every result register is an operand of the
+      // wait, or a copy / use of it may be scheduled in front of the wait (seen: the v_mov that assembles the bf6 operand)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(eg), "+v"(hx) :: "memory");
+#pragma unroll
+      for (int i = 0; i < TR; ++i) asm volatile("" : "+v"(ax[i][0]), "+v"(ax[i][1]), "+v"(ax[i][2]), "+v"(ax[i][3]));
+      if constexpr (six) {
+#pragma unroll
+        for (int j = 0; j < TC; ++j) asm volatile("" : "+v"(b6[j][0]), "+v"(b6[j][1]));
+      } else {
+#pragma unroll
+        for (int j = 0; j < TC; ++j) asm volatile("" : "+v"(bx[j][0]), "+v"(bx[j][1]), "+v"(bx[j][2]), "+v"(bx[j][3]));
+      }
       // E8M0 block scale supplied by this lane half for ITS group (half 0 -> block 0 = group 0): 2^(e_group - E) (e_group <= E; a group without gradient has e_group = 0 and zeros)
       int sc = 127 + eg - E;
       sc = sc < 0 ? 0 : (sc > 127 ? 127 : sc);
-      i32x8 b8[TC];
+      if constexpr (six) {
 #pragma unroll
-      for (int j = 0; j < TC; ++j) b8[j] = (i32x8){bx[j][0][0], bx[j][0][1], bx[j][1][0], bx[j][1][1], bx[j][2][0], bx[j][2][1], bx[j][3][0], bx[j][3][1]};
+        for (int i = 0; i < TR; ++i) {
+          const i32x8 a8 = {ax[i][0][0], ax[i][0][1], ax[i][1][0], ax[i][1][1], ax[i][2][0], ax[i][2][1], ax[i][3][0], ax[i][3][1]};
 #pragma unroll
-      for (int i = 0; i < TR; ++i) {
-        const i32x8 a8 = {ax[i][0][0], ax[i][0][1], ax[i][1][0], ax[i][1][1], ax[i][2][0], ax[i][2][1], ax[i][3][0], ax[i][3][1]};
+          for (int j = 0; j < TC; ++j) {
+            const i32x8 bb = {b6[j][0][0], b6[j][0][1], b6[j][0][2], b6[j][1][0], b6[j][1][1], b6[j][1][2], 0, 0};
+            const int sb = (int)(((unsigned)hx >> (8 * ((wc * TC + j) >> 1))) & 0xffu);      // this column tile's pair
+            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, bb, acc[i][j], 1, 3, 0, sc, 0, sb);
+          }
+          if (i == wc) accb = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, ones8, accb, 1, 1, 0, sc, 0, 127);      // (wc < TR: wave-uniform)
+        }
+      } else {
+        i32x8 b8[TC];
 #pragma unroll
-        for (int j = 0; j < TC; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8[j], acc[i][j], 1, 1, 0, sc, 0, 127);
-        if (i == wc) accb = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, ones8, accb, 1, 1, 0, sc, 0, 127);      // (wc < TR: wave-uniform)
+        for (int j = 0; j < TC; ++j) b8[j] = (i32x8){bx[j][0][0], bx[j][0][1], bx[j][1][0], bx[j][1][1], bx[j][2][0], bx[j][2][1], bx[j][3][0], bx[j][3][1]};
+#pragma unroll
+        for (int i = 0; i < TR; ++i) {
+          const i32x8 a8 = {ax[i][0][0], ax[i][0][1], ax[i][1][0], ax[i][1][1], ax[i][2][0], ax[i][2][1], ax[i][3][0], ax[i][3][1]};
+#pragma unroll
+          for (int j = 0; j < TC; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8[j], acc[i][j], 1, 1, 0, sc, 0, 127);
+          if (i == wc) accb = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, ones8, accb, 1, 1, 0, sc, 0, 127);      // (wc < TR: wave-uniform)
+        }
       }
     }
   }
