@@ -66,11 +66,13 @@ enum { AFX_PREC_F32 = 0, AFX_PREC_BF16X3 = 1, AFX_PREC_BF16 = 2, AFX_PREC_F16 = 
 
 /* CPPN(model_definition) — model/CPPN.py:10-139.  The configuration
  * nerf/run_nerf_acc.py:168-183 builds is accelerated end to end (ReLU, no skip block,
- * no view-direction head, one output channel); tanh / sine variants of it in the forward direction. */
+ * no view-direction head, one output channel); tanh / sine variants of it in the forward direction at every precision and in the
+ * backward direction at AFX_PREC_F32. */
 /* act_func of the hidden layers (model/CPPN.py:53-60).  ReLU is what nerf/run_nerf_acc.py trains and what every kernel takes.
  * tanh and sine (Sine(w0) on the first layer, Sine() behind it, CPPN.py:278-300) are evaluated by the FORWARD entry points
- * (afx_mlp_infer, afx_render_forward: inference, evaluation renders, density grids; without an input encoding); the backward entry points return
- * AFX_E_INVALID for them - a tanh / sine backward needs the activation VALUES per element, not a 1-bit mask. */
+ * (afx_mlp_infer, afx_render_forward: inference, evaluation renders, density grids; without an input encoding) at every precision.  The
+ * backward entry points (afx_mlp_backward, afx_render_backward) take them at AFX_PREC_F32 - the exact-fp32 chain kernel keeps d act / dz per
+ * element in the slot of the dZ_l stash (ReLU: one mask bit in LDS) - and return AFX_E_INVALID for them at the 16-bit precisions. */
 enum { AFX_ACT_RELU = 0, AFX_ACT_TANH = 1, AFX_ACT_SINE = 2 };
 
 typedef struct afx_model_desc {

@@ -592,8 +592,8 @@ static int launch_wgrad8_t(afx_ctx* c, const WgradArgs& w, const ReduceArgs& rd,
 static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws, size_t ws_bytes, float* grad_flat, hipStream_t st,
                         bool split = false, int64_t n_rays = 0, const int64_t* goff = nullptr) {
   const int F = c->d.width, N = c->d.n_hidden;
-  if (c->d.act != AFX_ACT_RELU)
-    return fail(AFX_E_INVALID, "backward: tanh / sine models are forward-only in this library (train them through the module's PyTorch operators)");
+  if (c->d.act != AFX_ACT_RELU && prec != AFX_PREC_F32)
+    return fail(AFX_E_INVALID, "backward: tanh / sine models train in the exact-fp32 kernels only (AFX_PREC_F32); the 16-bit kernels are forward-only for them");
   BwdLayout B = bwd_layout(c, prec, 0);
   const size_t fixed = head + B.fixed_bytes;
   const int TILE = bwd_tile(prec);

@@ -104,6 +104,10 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-
 __device__ __forceinline__ float act_value(float z, int act, float w) {
   return act == 1 ? tanhf(z) : enc_sincos(__fmul_rn(w, z), false);
 }
+// d act / dz for the backward chain of the exact-fp32 kernel: tanh' = 1 - h^2 (h = the activation's value), sin(w z)' = w cos(w z)
+__device__ __forceinline__ float act_slope(float z, float h, int act, float w) {
+  return act == 1 ? 1.f - h * h : w * enc_sincos(__fmul_rn(w, z), true);
+}
 
 // Per-lane description of the sample a lane's column holds.
 struct Sample {
@@ -256,6 +260,9 @@ __device__ __forceinline__ void ray_param(const ChainArgs& a, const Sample& sp, 
 // Fused chain kernel.  BWD=false: inference / forward.  BWD=true: recompute the forward,
 // then the input-gradient chain, stashing H_l and dZ_l of the tile for the weight-gradient
 // contraction over samples (k_wgrad_f32).
+// tanh / sine models (a.act != 0) train here too: where ReLU keeps one mask bit per activation in LDS, the forward half writes the
+// activation's slope d act / dz into the SLOT OF dZ_l (same lane, same address the lane later stores dZ_l to), and the backward half reads
+// it back just before it overwrites it - no extra memory, and the weight-gradient kernel sees the same two stashes.
 // ---------------------------------------------------------------------------------------
 template <int F, bool BWD>
 __global__ void __launch_bounds__(256, 1) k_chain_f32(const ChainArgs a) {
@@ -332,9 +339,22 @@ __global__ void __launch_bounds__(256, 1) k_chain_f32(const ChainArgs a) {
       for (int w = 0; w < MW; ++w) mw[w] = 0;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        if (!BWD && a.act != 0) {      // tanh / sine (inference only)
+        if (a.act != 0) {      // tanh / sine
+          f32x16 sl0;
 #pragma unroll
-          for (int j = 0; j < 16; ++j) h[t][j] = act_value(h[t][j], a.act, a.act_w0);
+          for (int j = 0; j < 16; ++j) {
+            const float z = h[t][j];
+            h[t][j] = act_value(z, a.act, a.act_w0);
+            if (BWD) sl0[j] = act_slope(z, h[t][j], a.act, a.act_w0);
+          }
+          if (BWD) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const size_t at = ((size_t)0 * a.stash_rows + m) * F + 32 * t + 8 * q + 4 * hh;
+              *(f32x4*)(a.stash_h + at) = (f32x4){h[t][4 * q], h[t][4 * q + 1], h[t][4 * q + 2], h[t][4 * q + 3]};
+              *(f32x4*)(a.stash_dz + at) = (f32x4){sl0[4 * q], sl0[4 * q + 1], sl0[4 * q + 2], sl0[4 * q + 3]};
+            }
+          }
           continue;
         }
 #pragma unroll
@@ -377,9 +397,21 @@ __global__ void __launch_bounds__(256, 1) k_chain_f32(const ChainArgs a) {
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[2], h[u >> 2][4 * (u & 3) + 2], acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[3], h[u >> 2][4 * (u & 3) + 3], acc, 0, 0, 0);
         }
-        if (!BWD && a.act != 0) {
+        if (a.act != 0) {
+          f32x16 sl1;
 #pragma unroll
-          for (int j = 0; j < 16; ++j) hn[t][j] = act_value(acc[j], a.act, 1.f);
+          for (int j = 0; j < 16; ++j) {
+            hn[t][j] = act_value(acc[j], a.act, 1.f);
+            if (BWD) sl1[j] = act_slope(acc[j], hn[t][j], a.act, 1.f);
+          }
+          if (BWD) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const size_t at = ((size_t)l * a.stash_rows + m) * F + 32 * t + 8 * q + 4 * hh;
+              *(f32x4*)(a.stash_h + at) = (f32x4){hn[t][4 * q], hn[t][4 * q + 1], hn[t][4 * q + 2], hn[t][4 * q + 3]};
+              *(f32x4*)(a.stash_dz + at) = (f32x4){sl1[4 * q], sl1[4 * q + 1], sl1[4 * q + 2], sl1[4 * q + 3]};
+            }
+          }
           continue;
         }
 #pragma unroll
@@ -450,13 +482,22 @@ __global__ void __launch_bounds__(256, 1) k_chain_f32(const ChainArgs a) {
       // ---------------- backward: dL/draw, then the input-gradient chain
       if (hh == 0) a.graw[m] = g;
       f32x16 dz[NT];
+      // tanh / sine: the slopes of layer l, as this lane left them in dZ_l's slot (every forward store has completed: step_begin waits
+      // for vmcnt(0) at each of the steps since)
+      auto slopes = [&](int l, int t, int q) { return *(const f32x4*)(a.stash_dz + ((size_t)l * a.stash_rows + m) * F + 32 * t + 8 * q + 4 * hh); };
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const uint32_t bits = mk[(N * MW + (t >> 1)) * 256 + tid] >> (16 * (t & 1));
+        const uint32_t bits = a.act != 0 ? 0u : mk[(N * MW + (t >> 1)) * 256 + tid] >> (16 * (t & 1));
         const f32x4* wp = (const f32x4*)(wout_perm + (hh * NT + t) * 16);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const f32x4 w4 = wp[q];
+          if (a.act != 0) {
+            const f32x4 s4 = slopes(N, t, q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dz[t][4 * q + e] = w4[e] * g * s4[e];
+            continue;
+          }
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             dz[t][4 * q + e] = __int_as_float(__float_as_int(w4[e] * g) & (((int)(bits << (31 - (4 * q + e)))) >> 31));
@@ -481,6 +522,15 @@ __global__ void __launch_bounds__(256, 1) k_chain_f32(const ChainArgs a) {
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[1], dz[u >> 2][4 * (u & 3) + 1], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[2], dz[u >> 2][4 * (u & 3) + 2], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[3], dz[u >> 2][4 * (u & 3) + 3], acc, 0, 0, 0);
+          }
+          if (a.act != 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const f32x4 s4 = slopes(l - 1, t, q);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) dn[t][4 * q + e] = acc[4 * q + e] * s4[e];
+            }
+            continue;
           }
           const uint32_t bits = mk[((l - 1) * MW + (t >> 1)) * 256 + tid] >> (16 * (t & 1));
 #pragma unroll

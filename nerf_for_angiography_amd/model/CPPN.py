@@ -149,16 +149,18 @@ class CPPN(nn.Module):
 
     @property
     def fused(self) -> bool:
-        """True when this configuration runs in the fused HIP kernels in BOTH directions (training included)."""
-        return self._act_name == "relu" and self.fused_forward
+        """True when this configuration runs in the fused HIP kernels in BOTH directions (training included): ReLU models at every
+        precision; tanh / sine models at precision "f32" (the exact-fp32 chain kernel keeps the activation's slope per element where
+        ReLU keeps one bit; the 16-bit kernels are forward-only for them)."""
+        return (self._act_name == "relu" or self.precision == "f32") and self.fused_forward
 
     @property
     def fused_forward(self) -> bool:
         """True when the FORWARD kernels take this configuration: the reference's trained geometry (no skip block, no view
         directions, one output channel) with any of its three activations.  tanh / sine models are evaluated by the kernels
         wherever no gradient is wanted (inference, evaluation renders, density grids: the activation is an epilogue of the same
-        chain kernel); with gradients they keep the module's PyTorch-ROCm operators (a tanh / sine backward needs the activation
-        values per element where ReLU needs one bit)."""
+        chain kernel); with gradients they train in the exact-fp32 kernels (precision "f32", see `fused`) and otherwise keep the
+        module's PyTorch-ROCm operators."""
         return ((self._act_name == "relu" or (self._act_name in ("tanh", "sine") and self.use_pos_enc == "none"))
                 and self.num_late_layers == 0 and not self.use_viewdirs
                 and self.num_output_channels == 1 and self.num_input_channels == 3 and self.use_bias

@@ -266,7 +266,7 @@ def test_fine_sampling_with_a_model_outside_the_fused_kernels():
     torch.manual_seed(6)
     md = dict(num_early_layers=3, num_late_layers=0, num_filters=64, num_input_channels=3, num_output_channels=1,
               num_input_channels_views=0, use_bias=True, pos_enc="none", pos_enc_basis=5, act_func="tanh", fourier_sigma=5,
-              num_img=1, device=torch.device(DEV))
+              num_img=1, device=torch.device(DEV), precision="bf16x3")      # (tanh at "f32" trains in the kernels: a fused configuration)
     m = CPPN(md).to(DEV)
     assert not m.fused
     with torch.no_grad():
@@ -493,11 +493,12 @@ def _act_model(g, act, layers=4, width=64, precision="f32", **extra):
 def test_tanh_sine_forward_kernels_vs_reference_fixture(golden, act, extra):
     """CPPN act_func 'tanh' / 'sine' (model/CPPN.py:53-60,278-300; G4 captured from the reference's CPPN with sine w0 = 15): the activation is an
     epilogue of the forward chain kernels.  Under torch.no_grad() the module's forward IS the kernel (exact-fp32 and split-bf16 at the
-    1e-5 / 5e-5 bars of the ReLU fixtures; f16 bounded), with gradients recorded it is the module's PyTorch operators, and both agree."""
+    1e-5 / 5e-5 bars of the ReLU fixtures; f16 bounded); with gradients recorded it is the exact-fp32 kernel pair at precision "f32" and the
+    module's PyTorch operators at the 16-bit precisions, and all agree."""
     g = golden(f"g4_cppn_none_{act}_4x64")
     x = T(g["x"])
     m = _act_model(g, act, **extra)
-    assert m.fused_forward and not m.fused
+    assert m.fused_forward and m.fused
     with torch.no_grad():
         y32 = m(x)
         assert rel_l2(y32.cpu().numpy(), g["y"]) < (1e-5 if act == "tanh" else 3e-5)      # sin(15 z): one ulp of z is 15 ulps of the argument
@@ -508,16 +509,24 @@ def test_tanh_sine_forward_kernels_vs_reference_fixture(golden, act, extra):
         m.precision = "f16"
         assert rel_l2(m(x).cpu().numpy(), g["y"]) < (3e-3 if act == "tanh" else 3e-2)      # sin(15 z): f16 operands in front of a steep argument
         m.precision = "f32"
-    y_ops = m(x)                                  # gradients recorded: operator route
+    y_k = m(x)                                    # gradients recorded, f32: the kernels (forward bit-identical to the no_grad launch)
+    assert y_k.requires_grad and torch.equal(y_k.detach(), y32)
+    y_k.sum().backward()
+    gk = torch.cat([p.grad.reshape(-1) for p in m._hip_params()]).double()
+    m.zero_grad(set_to_none=True)
+    m.precision = "f16"
+    assert not m.fused
+    y_ops = m(x)                                  # gradients recorded, 16-bit precision: operator route
     assert y_ops.requires_grad and rel_l2(y_ops.detach().cpu().numpy(), g["y"]) < 3e-5
     y_ops.sum().backward()
-    assert all(p.grad is not None for p in m._hip_params())
+    go = torch.cat([p.grad.reshape(-1) for p in m._hip_params()]).double()
+    assert float((gk - go).norm() / go.norm()) < (1e-5 if act == "tanh" else 2e-4)
 
 
 @pytest.mark.parametrize("act,extra", [("tanh", {}), ("sine", {"sine_weights": 2.0})])
 def test_tanh_sine_render_and_density_grid_vs_oracle(act, extra):
     """Evaluation renders (in-kernel ray generation, acc convention) and the density grid of tanh / sine models under torch.no_grad(), 8 hidden
-    layers of width 128, against the CPU oracle; asking for gradients through the fused renderer is refused."""
+    layers of width 128, against the CPU oracle; asking a 16-bit precision for gradients through the fused renderer is refused."""
     from oracle import angio_oracle as orc
     from nerf_for_angiography_amd.render import render_rays, density_grid
     torch.manual_seed(31)
@@ -535,8 +544,51 @@ def test_tanh_sine_render_and_density_grid_vs_oracle(act, extra):
         pts = orc.density_grid_points(100.0, 12)
         sig = torch.sigmoid(orc.cppn_forward(pts, cfg, params)).reshape(13, 13, 13)
         assert rel_l2(grid.cpu().numpy(), sig.numpy()) < 1e-4
+    m16 = _act_model(None, act, layers=8, width=128, precision="f16", **extra)      # 16-bit kernels: forward-only for tanh / sine
     with pytest.raises(NotImplementedError):
-        render_rays(m, o.to(DEV), d.to(DEV), 96, 1400.0, 1600.0, mode="acc")
+        render_rays(m16, o.to(DEV), d.to(DEV), 96, 1400.0, 1600.0, mode="acc")
+
+
+@pytest.mark.parametrize("act,extra,layers,width", [("tanh", {}, 4, 64), ("sine", {"sine_weights": 2.0}, 4, 64), ("tanh", {}, 8, 256),
+                                                    ("sine", {"sine_weights": 15}, 3, 128)])
+def test_tanh_sine_training_in_the_fp32_kernels_vs_oracle_autograd(act, extra, layers, width):
+    """tanh / sine models WITH gradients (model/CPPN.py:53-60,278-300): the exact-fp32 chain kernel keeps d act / dz per element in the slot
+    its dZ_l stash later overwrites (ReLU: one mask bit in LDS).  Fused render + MSE backward and the points-mode module forward/backward
+    (`get_predictions` route) against the CPU oracle's autograd."""
+    from oracle import angio_oracle as orc
+    from nerf_for_angiography_amd.render import render_rays
+    torch.manual_seed(17)
+    m = _act_model(None, act, layers=layers, width=width, **extra)
+    assert m.fused and m.precision == "f32"
+    with torch.no_grad():
+        m.output_linear[0].bias.fill_(-4.0)
+    r, s = 193, 70
+    o, d, tgt = _ref_iteration_problem(r, seed=13)
+    if act == "sine" and extra["sine_weights"] > 10:      # sin(15 W x): unit-scale inputs as SIREN wants them (the reference feeds its scene coordinates as they are)
+        o, near, far = o * 1e-3, 1.4, 1.6
+    else:
+        near, far = 1400.0, 1600.0
+    cfg = dict(num_early_layers=layers, num_filters=width, act_func=act, **extra)
+    params = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    pix_c, loss_c, grads_c = orc.loss_and_grads(o, d, tgt, cfg, params, near=near, far=far, n_samples=s, convention="acc")
+    out = render_rays(m, o.to(DEV), d.to(DEV), s, near, far, mode="acc")
+    loss = torch.nn.functional.mse_loss(out.rgb_map, tgt.to(DEV))
+    loss.backward()
+    assert rel_l2(out.rgb_map.detach().cpu().numpy(), pix_c.numpy()) < 1e-5
+    got = _grads_by_name(m)
+    assert set(grads_c) <= set(got)
+    for k, v in grads_c.items():
+        assert rel_l2(got[k], v.numpy()) < 2e-4, k
+    # points mode: module forward / backward on explicit query points
+    m.zero_grad(set_to_none=True)
+    pts = (torch.rand(777, 3, generator=torch.Generator().manual_seed(2)) * 2 - 1) * (0.1 if near < 10 else 100.0)
+    w = torch.randn(777, generator=torch.Generator().manual_seed(3))
+    leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    (orc.cppn_forward(pts, cfg, leaves).reshape(-1) * w).sum().backward()
+    (m(pts.to(DEV)).reshape(-1) * w.to(DEV)).sum().backward()
+    for k, v in leaves.items():
+        if v.grad is not None:
+            assert rel_l2(_grads_by_name(m)[k], v.grad.numpy()) < 2e-4, k
 
 
 # ------------------------------------------------------------------------------------------------ fused packed step (grid-march iteration)

@@ -125,8 +125,11 @@ def test_fused_path_refuses_cpu_tensors():
     m = CPPN(model_def(4, 64))
     with pytest.raises(AfxError, match="no CPU fallback"):
         render_rays(m, torch.zeros(4, 3), torch.zeros(4, 3), 32, 0.0, 1.0)
+    md16 = dict(model_def(4, 64, act="tanh"), precision="f16")      # tanh / sine train in the exact-fp32 kernels only
     with pytest.raises(NotImplementedError):
-        render_rays(CPPN(model_def(4, 64, act="tanh")), torch.zeros(4, 3), torch.zeros(4, 3), 32, 0.0, 1.0)
+        render_rays(CPPN(md16), torch.zeros(4, 3), torch.zeros(4, 3), 32, 0.0, 1.0)
+    with pytest.raises(NotImplementedError):
+        render_rays(CPPN(model_def(4, 64, late=4)), torch.zeros(4, 3), torch.zeros(4, 3), 32, 0.0, 1.0)
 
 
 # ---------------------------------------------------------------- CPPN mirror
