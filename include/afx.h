@@ -331,6 +331,16 @@ int afx_march_compact(const uint8_t* keep, const int64_t* offsets_in, const int6
 size_t afx_topk_workspace_bytes(int64_t n);
 int afx_topk_indices(const float* keys, int64_t n, int64_t k, int64_t* out_idx, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The ray batches of `n_batches` consecutive training iterations in one launch sequence: out_idx[b][k] = what afx_sample_keys(weights, n,
+ * u = NULL, seed, stream_id0 + b) followed by afx_topk_indices(k) returns, bit for bit (sample_pixel_rays draws one batch per iteration,
+ * nerf/run_nerf_acc.py:277; a draw is 11 launches of a few microseconds - launch latency, 5 % of the reference's 1.3 ms iteration - and the
+ * draws of different iterations are independent, so they share the launches: blockIdx.y = b).  workspace:
+ * afx_sample_batches_workspace_bytes(n, n_batches) bytes of device memory (the keys of every batch: n_batches x n floats); n < 2^32,
+ * n_batches <= 65535. */
+size_t afx_sample_batches_workspace_bytes(int64_t n, int32_t n_batches);
+int afx_sample_batches(const float* weights, int64_t n, uint64_t seed, uint64_t stream_id0, int32_t n_batches, int64_t k, int64_t* out_idx,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- Device-resident ray batches (sample_pixel_rays, nerf/nerf_helpers.py:137-150: weighted sampling without
  * replacement over all pixels of all training projections).  keys[i] = log(u_i) / w_i (Efraimidis-Spirakis): the k
  * largest keys are a weighted sample without replacement; u[n] supplied, or NULL: Philox stream (seed, stream_id).

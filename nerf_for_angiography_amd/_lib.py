@@ -70,6 +70,8 @@ _SIGS = {
                                      C.c_float, C.POINTER(RenderArgs), C.c_int, C.c_void_p]),
     "afx_topk_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "afx_topk_indices": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "afx_sample_batches_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
+    "afx_sample_batches": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "afx_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "afx_set_encoding_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "afx_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

@@ -1263,6 +1263,47 @@ extern "C" int afx_topk_indices(const float* keys, int64_t n, int64_t k, int64_t
   return AFX_OK;
 }
 
+// B independent draws per launch sequence: draw b = afx_sample_keys(stream_id0 + b) followed by afx_topk_indices, bit for bit
+extern "C" size_t afx_sample_batches_workspace_bytes(int64_t n, int32_t n_batches) {
+  const int64_t nb = (n + SEL_PER_BLOCK - 1) / SEL_PER_BLOCK, B = n_batches > 0 ? n_batches : 1;
+  return (size_t)B * ((size_t)(n > 0 ? n : 0) * 4 + (size_t)SEL_BINS * 4 + sizeof(SelState) + (size_t)2 * (nb > 0 ? nb : 1) * 4) + 1024;
+}
+
+extern "C" int afx_sample_batches(const float* weights, int64_t n, uint64_t seed, uint64_t stream_id0, int32_t n_batches, int64_t k,
+                                  int64_t* out_idx, void* workspace, size_t workspace_bytes, void* stream) {
+  if (k == 0 || n_batches == 0) return AFX_OK;
+  if (n <= 0 || k < 0 || k > n || n >= ((int64_t)1 << 32) || n_batches < 0 || n_batches > 65535)
+    return fail(AFX_E_INVALID, "afx_sample_batches: need 0 <= k <= n < 2^32 and 0 <= n_batches <= 65535");
+  if (!out_idx || !workspace) return fail(AFX_E_INVALID, "afx_sample_batches: null argument");
+  if (workspace_bytes < afx_sample_batches_workspace_bytes(n, n_batches)) return fail(AFX_E_WORKSPACE, "afx_sample_batches: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned B = (unsigned)n_batches;
+  const int64_t nb = (n + SEL_PER_BLOCK - 1) / SEL_PER_BLOCK;
+  char* w = (char*)workspace;
+  float* keys = (float*)w;            w += ((size_t)B * n * 4 + 255) / 256 * 256;
+  uint32_t* hist = (uint32_t*)w;      w += (size_t)B * SEL_BINS * 4;
+  SelState* state = (SelState*)w;     w += ((size_t)B * sizeof(SelState) + 255) / 256 * 256;
+  uint32_t* cnt_gt = (uint32_t*)w;
+  uint32_t* cnt_eq = cnt_gt + (size_t)B * nb;
+  int hb = (int)((n + 256 * 16 - 1) / (256 * 16));
+  if (hb < 1) hb = 1;
+  if (hb > 2048) hb = 2048;
+  hipLaunchKernelGGL(k_sample_keys, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, st, weights, n, (const float*)nullptr, seed, stream_id0, keys);
+  hipLaunchKernelGGL(k_sel_init, dim3(1, B), dim3(256), 0, st, state, (uint32_t)k, hist);
+  const int shifts[3] = {21, 10, 0};
+  const uint32_t binmask[3] = {0x7ffu, 0x7ffu, 0x3ffu}, himask[3] = {0u, 0xffe00000u, 0xfffffc00u};
+  for (int p = 0; p < 3; ++p) {
+    hipLaunchKernelGGL(k_sel_hist, dim3(hb, B), dim3(256), 0, st, (const float*)keys, n, (const SelState*)state, himask[p], shifts[p], binmask[p], hist);
+    hipLaunchKernelGGL(k_sel_scan, dim3(1, B), dim3(256), 0, st, hist, state, shifts[p]);
+  }
+  hipLaunchKernelGGL(k_sel_count, dim3((unsigned)nb, B), dim3(256), 0, st, (const float*)keys, n, (const SelState*)state, cnt_gt, cnt_eq);
+  hipLaunchKernelGGL(k_sel_offsets, dim3(1, B), dim3(1024), 0, st, cnt_gt, cnt_eq, nb);
+  hipLaunchKernelGGL(k_sel_write, dim3((unsigned)nb, B), dim3(256), 0, st, (const float*)keys, n, (const SelState*)state, (const uint32_t*)cnt_gt,
+                     (const uint32_t*)cnt_eq, k, out_idx);
+  HIPCHK(hipGetLastError());
+  return AFX_OK;
+}
+
 extern "C" int afx_gather_rays(const float* origins, const float* dirs, const float* pixels, const int64_t* idx, int64_t k,
                                float* origins_out, float* dirs_out, float* pixels_out, void* stream) {
   if (k <= 0) return AFX_OK;

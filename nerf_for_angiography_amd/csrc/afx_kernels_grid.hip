@@ -326,19 +326,23 @@ __global__ void __launch_bounds__(256) k_pack_groups(const int64_t* offsets, con
 // --- device ray sampler (sample_pixel_rays, nerf/nerf_helpers.py:137-150): weighted sampling WITHOUT replacement of k of n
 // rays.  Efraimidis-Spirakis keys: key_i = u_i^(1/w_i) (log form: log(u_i)/w_i), the k largest keys are a weighted sample
 // without replacement; u from Philox (perf mode) or supplied.  The top-k selection is the radix select below.
+// (blockIdx.y = batch b of afx_sample_batches: Philox stream `stream + b`, keys row b; a plain call has one row)
 __global__ void k_sample_keys(const float* weights, int64_t n, const float* u_in, uint64_t seed, uint64_t stream, float* keys) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float w = weights ? weights[i] : 1.f;
-  float u = u_in ? u_in[i] : philox_uniform(seed, stream, (uint64_t)i);
+  float u = u_in ? u_in[i] : philox_uniform(seed, stream + blockIdx.y, (uint64_t)i);
   u = fmaxf(u, 5.9604645e-08f);
-  keys[i] = w > 0.f ? logf(u) / w : -INFINITY;
+  keys[(int64_t)blockIdx.y * n + i] = w > 0.f ? logf(u) / w : -INFINITY;
 }
 // --- top-k by radix select (the sampler's selection step; a full device sort of the 900 000 keys was 13 % of the reference's
 // training iteration).  Keys map to uint32 monotonically; three histogram passes (11 + 11 + 10 bits, each over the keys that
 // match the prefix found so far) locate the k-th largest key T exactly; the selected set {key > T} plus the first `need_eq`
 // keys equal to T (lowest index first) is then written in ASCENDING INDEX order by a counted, two-level compaction - no
 // atomics on the output, so the result is deterministic.  Byte/integer work, HBM-bound: 5 reads of the key array.
+// Every kernel takes blockIdx.y as a batch index (afx_sample_batches: B independent selections per launch - at 900 000 keys a selection is
+// 11 launches of a few microseconds each, i.e. launch latency; B of them share the 11 launches): row b of keys [B][n], hist [B][SEL_BINS],
+// state [B], counts [B][nb], output [B][k].
 __device__ __forceinline__ uint32_t key_bits(float f) {
   const uint32_t b = __float_as_uint(f);
   return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
@@ -348,12 +352,14 @@ constexpr int SEL_BINS = 2048;
 constexpr int SEL_PER_BLOCK = 1024;      // elements per block of the compaction kernels (256 threads x 4)
 
 __global__ void __launch_bounds__(256) k_sel_init(SelState* st, uint32_t k, uint32_t* hist) {
+  st += blockIdx.y; hist += (size_t)blockIdx.y * SEL_BINS;
   if (threadIdx.x == 0) { st->prefix = 0; st->remaining = k; }
   for (int i = threadIdx.x; i < SEL_BINS; i += 256) hist[i] = 0;
 }
 __global__ void __launch_bounds__(256) k_sel_hist(const float* keys, int64_t n, const SelState* st, uint32_t himask, int shift,
                                                   uint32_t binmask, uint32_t* hist) {
   __shared__ uint32_t h[SEL_BINS];
+  keys += (int64_t)blockIdx.y * n; st += blockIdx.y; hist += (size_t)blockIdx.y * SEL_BINS;
   for (int i = threadIdx.x; i < SEL_BINS; i += 256) h[i] = 0;
   __syncthreads();
   const uint32_t prefix = st->prefix;
@@ -369,6 +375,7 @@ __global__ void __launch_bounds__(256) k_sel_hist(const float* keys, int64_t n, 
 __global__ void __launch_bounds__(256) k_sel_scan(uint32_t* hist, SelState* st, int shift) {
   __shared__ uint32_t part[256];
   __shared__ uint32_t above[256];      // keys in the groups above group t
+  st += blockIdx.y; hist += (size_t)blockIdx.y * SEL_BINS;
   const int t = threadIdx.x;           // group t = bins [8 (255 - t), 8 (255 - t) + 7], i.e. t = 0 is the top group
   const uint32_t r = st->remaining;    // read by every thread BEFORE the barriers; one thread rewrites it behind them
   uint32_t c[8], s = 0;
@@ -399,6 +406,7 @@ __global__ void __launch_bounds__(256) k_sel_scan(uint32_t* hist, SelState* st, 
 // per block of 1024 keys: how many are above the threshold / equal to it
 __global__ void __launch_bounds__(256) k_sel_count(const float* keys, int64_t n, const SelState* st, uint32_t* cnt_gt, uint32_t* cnt_eq) {
   __shared__ uint32_t sg[256], se[256];
+  keys += (int64_t)blockIdx.y * n; st += blockIdx.y; cnt_gt += (size_t)blockIdx.y * gridDim.x; cnt_eq += (size_t)blockIdx.y * gridDim.x;
   const uint32_t T = st->prefix;
   const int64_t base = (int64_t)blockIdx.x * SEL_PER_BLOCK + 4 * threadIdx.x;
   uint32_t g = 0, e = 0;
@@ -416,6 +424,7 @@ __global__ void __launch_bounds__(256) k_sel_count(const float* keys, int64_t n,
 // one block: exclusive prefix sums of the per-block counts, in place
 __global__ void __launch_bounds__(1024) k_sel_offsets(uint32_t* cnt_gt, uint32_t* cnt_eq, int64_t nb) {
   __shared__ uint32_t pg[1024], pe[1024];
+  cnt_gt += (size_t)blockIdx.y * nb; cnt_eq += (size_t)blockIdx.y * nb;
   const int t = threadIdx.x;
   const int64_t per = (nb + 1023) / 1024, b0 = t * per, b1 = b0 + per < nb ? b0 + per : nb;
   uint32_t g = 0, e = 0;
@@ -434,6 +443,8 @@ __global__ void __launch_bounds__(1024) k_sel_offsets(uint32_t* cnt_gt, uint32_t
 __global__ void __launch_bounds__(256) k_sel_write(const float* keys, int64_t n, const SelState* st, const uint32_t* off_gt,
                                                    const uint32_t* off_eq, int64_t k, int64_t* out_idx) {
   __shared__ uint32_t sg[256], se[256];
+  keys += (int64_t)blockIdx.y * n; st += blockIdx.y; off_gt += (size_t)blockIdx.y * gridDim.x; off_eq += (size_t)blockIdx.y * gridDim.x;
+  out_idx += (int64_t)blockIdx.y * k;
   const uint32_t T = st->prefix, need_eq = st->remaining;
   const int t = threadIdx.x;
   const int64_t base = (int64_t)blockIdx.x * SEL_PER_BLOCK + 4 * t;

@@ -163,6 +163,8 @@ def main(argv=None):
     os.makedirs(args.log_dir, exist_ok=True)
     log = open(os.path.join(args.log_dir, 'train_log.jsonl'), 'a')
     highest_psnr, highest_iter, history = 0.0, 0, []
+    if not args.host_sampler:      # the batches of 16 iterations per launch sequence
+        ray_batches = _engine.RayBatchSampler(tab_o, tab_d, tab_pix, tab_w, img_sample_size, seed=args.seed, prefetch=16)
     new_lr_coarse = coarse_lr
     loss_coarse = torch.tensor(float('nan'), device=device)
     n_marched = 0
@@ -175,8 +177,7 @@ def main(argv=None):
             batch_origins, batch_directions, batch_pix_vals = sample_pixel_rays(train_ray_df, img_sample_size, device,
                                                                                weights='distance_pixel_value')
         else:
-            batch_origins, batch_directions, batch_pix_vals, _ = _engine.sample_rays(tab_o, tab_d, tab_pix, tab_w, img_sample_size,
-                                                                                     seed=args.seed, stream_id=n_iter)
+            batch_origins, batch_directions, batch_pix_vals, _ = ray_batches.draw(n_iter)      # == sample_rays(..., seed, stream_id=n_iter)
         coarse_optimizer.zero_grad()
         if args.march != 'dense':
             # the reference's iteration body, run_nerf_acc.py:284-306

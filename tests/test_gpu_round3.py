@@ -844,3 +844,25 @@ def test_six_bit_h_stash_variant_matches_the_default_library(case):
         g32 = torch.cat([p.grad.reshape(-1) for p in m32._hip_params()]).double()
         e8, e6 = float((g8 - g32).norm() / g32.norm()), float((g6 - g32).norm() / g32.norm())
         assert e6 < TOL["f16s8"]["grad"] and e6 < 1.5 * e8 + 1e-4, (e8, e6)
+
+
+@pytest.mark.parametrize("n,k,prefetch", [(900000, 5625, 16), (20000, 512, 5), (1025, 1025, 3), (7, 3, 1)])
+def test_batched_ray_sampler_equals_the_per_iteration_draws(n, k, prefetch):
+    """afx_sample_batches / engine.RayBatchSampler: the batches of `prefetch` consecutive iterations from ONE launch sequence (blockIdx.y = the
+    iteration) are, index for index, what sample_rays(seed, stream_id) draws per iteration (sample_pixel_rays, nerf/nerf_helpers.py:137-150);
+    stream ids outside the prefetched block start a new block; ragged sizes, k = n, zero weights."""
+    from nerf_for_angiography_amd import engine as eng
+    g = torch.Generator().manual_seed(n)
+    o, d, pix = torch.randn(n, 3, generator=g).to(DEV), torch.randn(n, 3, generator=g).to(DEV), torch.rand(n, generator=g).to(DEV)
+    w = torch.rand(n, generator=g) + 0.01
+    if n > 100 and k < n:
+        w[::13] = 0.0
+    w = w.to(DEV)
+    sampler = eng.RayBatchSampler(o, d, pix, w, k, seed=11, prefetch=prefetch)
+    for sid in list(range(4, 4 + 2 * prefetch + 1)) + [2, 1000, 1001]:
+        bo, bd, bp, bidx = sampler.draw(sid)
+        so, sd, sp, sidx = eng.sample_rays(o, d, pix, w, k, seed=11, stream_id=sid)
+        assert torch.equal(bidx, sidx), sid
+        assert torch.equal(bo, so) and torch.equal(bd, sd) and torch.equal(bp, sp)
+    with pytest.raises(ValueError):
+        eng.RayBatchSampler(o, d, pix, w, n + 1)

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import torch
 from nerf_for_angiography_amd.model.CPPN import CPPN
 from nerf_for_angiography_amd.render import train_step_packed_mse
-from nerf_for_angiography_amd.engine import sample_rays
+from nerf_for_angiography_amd.engine import sample_rays, RayBatchSampler
 from nerf_for_angiography_amd.nerf.nerf_helpers import get_predictions
 from nerf_for_angiography_amd.nerf.nerf_helpers_acc import acc_ray_marching, acc_render_volume_density
 from nerf_for_angiography_amd.nerf.occupancy import OccupancyGrid
@@ -43,9 +43,10 @@ grid._binary = mask
 print(f"occupied cells: {float(mask.float().mean()) * 100:.1f} %")
 R, S, near, far = 5625, 300, 1400.0, 1600.0
 n, tot = [0], [0]
+batches = RayBatchSampler(tab_o, tab_d, tab_p, tab_w, R, seed=0, prefetch=int(os.environ.get("PREFETCH", 16))) if os.environ.get("PREFETCH", "16") != "0" else None
 def it():
     n[0] += 1
-    o, d, tgt, _ = sample_rays(tab_o, tab_d, tab_p, tab_w, R, seed=0, stream_id=n[0])
+    o, d, tgt, _ = batches.draw(n[0]) if batches else sample_rays(tab_o, tab_d, tab_p, tab_w, R, seed=0, stream_id=n[0])
     opt.zero_grad(set_to_none=True)
     with torch.no_grad():
         out = acc_ray_marching(m, grid, aabb, o, d, S, near, far, 1e-2, 1e-4, return_packed=(mode == "fused"))

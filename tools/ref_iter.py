@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import torch
 from nerf_for_angiography_amd.model.CPPN import CPPN
 from nerf_for_angiography_amd.render import train_step_mse
-from nerf_for_angiography_amd.engine import RenderSpec, sample_rays
+from nerf_for_angiography_amd.engine import RenderSpec, sample_rays, RayBatchSampler
 
 dev = torch.device("cuda:0")
 layers, width = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (4, 128)
@@ -29,9 +29,10 @@ if md["pos_enc"] == "barf":
 opt = torch.optim.Adam(m.parameters(), lr=1e-4)
 R, S = 5625, 300
 n = [0]
+batches = RayBatchSampler(tab_o, tab_d, tab_p, tab_w, R, seed=0, prefetch=int(os.environ.get("PREFETCH", 16))) if os.environ.get("PREFETCH", "16") != "0" else None
 def it():
     n[0] += 1
-    o, d, tgt, _ = sample_rays(tab_o, tab_d, tab_p, tab_w, R, seed=0, stream_id=n[0])
+    o, d, tgt, _ = batches.draw(n[0]) if batches else sample_rays(tab_o, tab_d, tab_p, tab_w, R, seed=0, stream_id=n[0])
     spec = RenderSpec(n_rays=R, n_samples=S, origins=o, dirs=d, mode="acc", t_near=1400.0, t_far=1600.0)
     opt.zero_grad(set_to_none=True); train_step_mse(m, spec, tgt); opt.step()
 for _ in range(10): it()
