@@ -544,7 +544,7 @@ static int launch_wgrad16_t(afx_ctx* c, const WgradArgs& w, const ReduceArgs& rd
     // + the first layer (encoded inputs) and the fourier-coefficient contraction as extra grid rows
     hipLaunchKernelGGL((k_wgrad_bf16<F, H16>), dim3(w.n_splits, N + (w.enc16 ? 1 + (w.coef_cols > 0 ? 1 : 0) : 0)), dim3(512), lds, st, w);
   }
-  if (w.small_groups) hipLaunchKernelGGL(k_small_from_groups<F>, dim3(rd.n_small), dim3(F), 0, st, w);
+  if (w.small_groups) hipLaunchKernelGGL(k_small_from_groups<F>, dim3(rd.n_small), dim3(F, 4), 0, st, w);
   else hipLaunchKernelGGL((k_small_grads_bf16<F, H16>), dim3(rd.n_small, F / 64), dim3(256), 0, st, w);
   hipLaunchKernelGGL(k_reduce_w<F>, dim3((F * F + 255) / 256, N + 1), dim3(256), 0, st, rd);
   hipLaunchKernelGGL(k_reduce_b<F>, dim3(1, N + 2), dim3(F), 0, st, rd);
@@ -574,7 +574,7 @@ static int launch_wgrad8_t(afx_ctx* c, const WgradArgs& w, const ReduceArgs& rd,
       hipLaunchKernelGGL((k_wgrad_s8<F, false>), dim3(w.n_splits, extra), dim3(512), lds, st, w1);
     } else hipLaunchKernelGGL((k_wgrad_s8<F, H6>), dim3(w.n_splits, N + extra), dim3(512), lds, st, w);
   }
-  hipLaunchKernelGGL(k_small_from_groups<F>, dim3(rd.n_small), dim3(F), 0, st, w);
+  hipLaunchKernelGGL(k_small_from_groups<F>, dim3(rd.n_small), dim3(F, 4), 0, st, w);
   if (w.no_sw) hipLaunchKernelGGL(k_wout_stash8<F>, dim3(rd.n_small), dim3(2 * F), 0, st, w);      // output layer from the stash of H_N (same records)
   hipLaunchKernelGGL(k_reduce_w<F>, dim3((F * F + 255) / 256, N + 1), dim3(256), 0, st, rd);
   hipLaunchKernelGGL(k_reduce_b<F>, dim3(1, N + 2), dim3(F), 0, st, rd);

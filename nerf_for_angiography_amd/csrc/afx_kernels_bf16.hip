@@ -1583,8 +1583,11 @@ __global__ void __launch_bounds__(256) k_small_grads_bf16(const WgradArgs a) {
 // the chain kernel left where H_N's stash would have been.  grid = n_small blocks, block = F threads (thread p =
 // stash position, feature fperm(p)); block b sums its contiguous range of groups in order.
 template <int F>
-__global__ void __launch_bounds__(F) k_small_from_groups(const WgradArgs a) {
-  const int p = threadIdx.x, f = fperm(p);
+__global__ void __launch_bounds__(4 * F) k_small_from_groups(const WgradArgs a) {
+  // block = (F, 4): four interleaved group sequences per block (combined in fixed order through LDS) - the record loop is a chain of dependent
+  // loads (group -> ray -> dod), and at the reference's batch sizes four times the waves in flight is what shortens it
+  __shared__ float red[3][6][F];
+  const int p = threadIdx.x, f = fperm(p), q = threadIdx.y;
   const int64_t ngroups = a.rows >> 5;
   const int64_t per = (ngroups + gridDim.x - 1) / gridDim.x;
   int64_t g0 = (int64_t)blockIdx.x * per, g1 = g0 + per;
@@ -1592,8 +1595,8 @@ __global__ void __launch_bounds__(F) k_small_from_groups(const WgradArgs a) {
   constexpr int RS = 3 * F + 8;
   const float* base = a.records ? a.records : (const float*)((const char*)a.stash_h + (size_t)a.n_hidden * a.stride_rows * F * a.stash_esz);
   float aw = 0.f, a0 = 0.f, ax = 0.f, ay = 0.f, az = 0.f, sg = 0.f;
-#pragma unroll 4
-  for (int64_t g = g0; g < g1; ++g) {
+#pragma unroll 2
+  for (int64_t g = g0 + q; g < g1; g += 4) {
     const float* rec = base + g * RS;
     // (split phases: SW and sum g were formed with g' = g / dod[ray]; a group never straddles rays)
     // (the groups that pad the last tile belong to no ray: their sums are zero, and neither group_ray nor dod has an entry for them)
@@ -1617,6 +1620,14 @@ __global__ void __launch_bounds__(F) k_small_from_groups(const WgradArgs a) {
     ay += fmaf(c4[1], s0, d4[0] * s1);
     az += fmaf(c4[2], s0, d4[1] * s1);
     sg += a.no_sw ? 0.f : d4[2] * ds;
+  }
+  if (q > 0) { float* r = &red[q - 1][0][p]; r[0] = aw; r[F] = a0; r[2 * F] = ax; r[3 * F] = ay; r[4 * F] = az; r[5 * F] = sg; }
+  __syncthreads();
+  if (q > 0) return;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float* r = &red[i][0][p];
+    aw += r[0]; a0 += r[F]; ax += r[2 * F]; ay += r[3 * F]; az += r[4 * F]; sg += r[5 * F];
   }
   const size_t SS = (size_t)F * a.k0pad + 2 * F + 4;
   float* P = a.partial_s + (size_t)blockIdx.x * SS;

@@ -685,6 +685,7 @@ __global__ void k_reduce_w(const ReduceArgs a) {
   const int row = e / ncols, c = e % ncols;
   if (c >= ncr) return;
   float s = 0.f;
+#pragma unroll 8      // (independent loads in flight: the loop is latency-bound at the reference's batch sizes)
   for (int sp = 0; sp < a.n_splits; ++sp) s += a.partial[((size_t)layer * a.n_splits + sp) * F * F + e];
   // flat layout: W0[F,k0] b0[F] then (W_l[F,F] b_l[F])*, Wout[F] bout
   size_t off = layer == 0 ? 0 : (size_t)F * a.k0 + F + (size_t)(layer - 1) * (F * F + F);
@@ -698,6 +699,7 @@ __global__ void k_reduce_b(const ReduceArgs a) {
   const int y = blockIdx.y, f = threadIdx.x;
   if (a.hidden_only && ((y == 0 && !a.layer0_mfma) || y == a.n_hidden + 1)) return;
   float s = 0.f, sg = 0.f;
+#pragma unroll 8
   for (int sp = 0; sp < a.n_splits; ++sp) {
     const float* P = a.partial2 + ((size_t)y * a.n_splits + sp) * (F + 4);
     s += P[f];

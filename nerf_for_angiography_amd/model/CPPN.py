@@ -13,6 +13,21 @@ from __future__ import annotations
 import numpy as np
 import torch
 import torch.nn as nn
+from torch.optim.optimizer import register_optimizer_step_post_hook
+
+
+# Optimizer steps the version counters cannot see: torch.optim's FUSED implementations (Adam(fused=True) ...) update the parameters through
+# one multi-tensor kernel that bumps no tensor's `_version`, so a cache of re-tiled weights keyed on versions alone goes stale after them
+# (seen: 10 fused Adam steps rendered with the initial weights).  A global post-hook counts every optimizer step of the process; the count is
+# part of the cache key (CPPN._prepared) - at worst one re-tiling launch (~5 us) per call behind an unrelated optimizer's step.
+_OPT_STEPS = [0]
+
+
+def _count_optimizer_step(optimizer, args, kwargs):
+    _OPT_STEPS[0] += 1
+
+
+register_optimizer_step_post_hook(_count_optimizer_step)
 
 
 class Sine(nn.Module):
@@ -231,8 +246,9 @@ class CPPN(nn.Module):
 
     def invalidate(self):
         """Drop the cached re-tiled weights.  Needed after writes the version counters cannot see: `p.data.copy_(...)`,
-        `p.data.normal_()`, initialisers applied through `.data`, EMA code.  (Optimizer steps, `load_state_dict`, in-place
-        ops on the parameters and writes to `flat_params` are tracked automatically.)"""
+        `p.data.normal_()`, initialisers applied through `.data`, EMA code.  (Optimizer steps - every torch.optim step of the process is
+        counted, fused implementations included -, `load_state_dict`, in-place ops on the parameters and writes to `flat_params` are
+        tracked automatically.)"""
         if self._engine is not None:
             self._engine._prepared.clear()
 
@@ -249,8 +265,9 @@ class CPPN(nn.Module):
 
     def _prepared(self):
         """Prepared (re-tiled) weights for the current parameter values.  Cached on the version counters of the
-        parameters (bumped by every in-place optimizer update / load_state_dict) and of the flat buffer itself (bumped by
-        direct writes such as a broadcast); parameters that no longer alias the flat buffer are re-flattened first.
+        parameters (bumped by in-place updates / load_state_dict), the process-wide count of optimizer steps (fused optimizers
+        bump no version counter) and the version of the flat buffer itself (bumped by direct writes such as a broadcast);
+        parameters that no longer alias the flat buffer are re-flattened first.
         Writes through `.data` bump no counter: call `invalidate()` after them."""
         self._check_views()
         aux_key = None
@@ -258,7 +275,7 @@ class CPPN(nn.Module):
             aux_key = float(self.barf_alpha)
         elif self.use_pos_enc == "fourier":
             aux_key = self.fourier_coefficients._version
-        key = (self._flat._version, self._flat.data_ptr(), self.precision, aux_key,
+        key = (self._flat._version, self._flat.data_ptr(), self.precision, aux_key, _OPT_STEPS[0],
                tuple(p._version for p in self._hip_params()))
         cached = self.engine._prepared.get(self.precision)
         if cached is not None and cached[1] == key:

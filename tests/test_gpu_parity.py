@@ -269,12 +269,14 @@ def test_fused_render_dense_golden(golden):
         assert rel_l2(got[k], g["dense26_grad__" + k]) < 1e-4, k
 
 
-def test_adam_steps_golden(golden):
-    """10 optimizer steps (PyTorch Adam on the flat-buffer views) reproduce the reference's weights."""
+@pytest.mark.parametrize("fused", [False, True])
+def test_adam_steps_golden(golden, fused):
+    """10 optimizer steps (PyTorch Adam on the flat-buffer views; its default implementation and the fused multi-tensor kernel the training
+    driver selects) reproduce the reference's weights."""
     from nerf_for_angiography_amd.render import render_rays
     g, m, near, far, s = _c1(golden)
     o, d, tgt = T(g["o"]), T(g["d"]), T(g["target"])
-    opt = torch.optim.Adam(list(m.parameters()), lr=1e-4)
+    opt = torch.optim.Adam(list(m.parameters()), lr=1e-4, fused=fused)
     for it in range(10):
         opt.zero_grad()
         loss = torch.nn.functional.mse_loss(render_rays(m, o, d, s, near, far, mode="acc").rgb_map, tgt)

@@ -866,3 +866,30 @@ def test_batched_ray_sampler_equals_the_per_iteration_draws(n, k, prefetch):
         assert torch.equal(bo, so) and torch.equal(bd, sd) and torch.equal(bp, sp)
     with pytest.raises(ValueError):
         eng.RayBatchSampler(o, d, pix, w, n + 1)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_prepared_weight_cache_follows_optimizer_steps(fused):
+    """The re-tiled weights are cached between calls; torch.optim's fused implementations update the parameters without bumping any
+    version counter (found when the driver moved to Adam(fused=True): ten steps rendered with the initial weights).  Every optimizer step of
+    the process is counted into the cache key: training steps and the no-grad renders between them see the current weights."""
+    from nerf_for_angiography_amd.render import render_rays
+    torch.manual_seed(3)
+    m = make_model(4, 64, precision="f16s8")
+    with torch.no_grad():
+        m.output_linear[0].bias.fill_(-4.0)
+    o, d, tgt = _ref_iteration_problem(200, seed=5)
+    o, d, tgt = o.to(DEV), d.to(DEV), tgt.to(DEV)
+    opt = torch.optim.Adam(list(m.parameters()), lr=1e-2, fused=fused)
+    with torch.no_grad():
+        before = render_rays(m, o, d, 64, 1400.0, 1600.0, mode="acc").rgb_map.clone()
+    for _ in range(3):
+        opt.zero_grad()
+        torch.nn.functional.mse_loss(render_rays(m, o, d, 64, 1400.0, 1600.0, mode="acc").rgb_map, tgt).backward()
+        opt.step()
+    with torch.no_grad():
+        after = render_rays(m, o, d, 64, 1400.0, 1600.0, mode="acc").rgb_map
+        fresh = make_model(4, 64, precision="f16s8")
+        fresh.load_state_dict(m.state_dict())
+        want = render_rays(fresh, o, d, 64, 1400.0, 1600.0, mode="acc").rgb_map
+    assert not torch.equal(before, after) and torch.equal(after, want)

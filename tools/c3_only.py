@@ -22,7 +22,7 @@ m = CPPN(md).to(dev)
 with torch.no_grad():
     m.output_linear[0].weight.mul_(4.0); m.output_linear[0].bias.fill_(-5.0)
 m.engine.max_workspace_bytes = 128 << 30
-opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+opt = torch.optim.Adam(m.parameters(), lr=1e-4, fused=True)
 if os.environ.get("WS_FIRST"):
     ws = m.engine._workspace(128 << 30, dev)      # allocate the backward workspace before anything else of size
     fill = os.environ.get("WS_FILL")

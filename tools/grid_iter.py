@@ -28,7 +28,7 @@ md = dict(num_early_layers=layers, num_late_layers=0, num_filters=width, num_inp
 m = CPPN(md).to(dev)
 with torch.no_grad():
     m.output_linear[0].bias.fill_(-3.0)
-opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+opt = torch.optim.Adam(m.parameters(), lr=1e-4, fused=os.environ.get("ADAM_FUSED", "1") != "0")      # (one multi-tensor kernel instead of the foreach sequence)
 aabb = torch.tensor([-100.0, -100, -100, 100, 100, 100], device=dev)
 grid = OccupancyGrid(roi_aabb=aabb, resolution=128).to(dev)
 res = 128

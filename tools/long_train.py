@@ -66,7 +66,7 @@ def main():
         m = CPPN(dict(md, precision=prec)).to(dev)
         with torch.no_grad():
             m.output_linear[0].bias.fill_(-5.0)
-        opt = torch.optim.Adam(list(m.parameters()), lr=args.lr)
+        opt = torch.optim.Adam(list(m.parameters()), lr=args.lr, fused=True)
         gen = torch.Generator().manual_seed(1234 + args.seed)
         hist = []
         t0 = time.time()

@@ -36,7 +36,7 @@ def timeit(fn, warm=1, steps=3, min_time=1.0):
 
 out = {}
 for name, (W, S) in {"C2 256^2x64": (256, 64), "C4 512^2x128 (1 GPU)": (512, 128), "C5 1024^2x256 (1 GPU)": (1024, 256)}.items():
-    m = model(); opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    m = model(); opt = torch.optim.Adam(m.parameters(), lr=1e-4, fused=True)
     o, d, m44, _, _ = get_ray_values(20.0, 0.0, 0.0, np.array([0, 0, 1500.0]), W, W, 13.0 * W, dev)
     pose = torch.from_numpy(m44[None]).to(dev); tgt = torch.rand(W * W, device=dev)
     spec = projection_spec(pose, W, W, 13.0 * W, S, 1400.0, 1600.0)
@@ -49,7 +49,7 @@ for name, (W, S) in {"C2 256^2x64": (256, 64), "C4 512^2x128 (1 GPU)": (512, 128
 for enc in ("barf", "fourier"):
     W, S = 512, 128
     m = opt = None; import gc; gc.collect(); torch.cuda.empty_cache()       # the previous model's 128 GiB workspace
-    m = model(enc=enc); opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    m = model(enc=enc); opt = torch.optim.Adam(m.parameters(), lr=1e-4, fused=True)
     o, d, m44, _, _ = get_ray_values(20.0, 0.0, 0.0, np.array([0, 0, 1500.0]), W, W, 13.0 * W, dev)
     pose = torch.from_numpy(m44[None]).to(dev); tgt = torch.rand(W * W, device=dev)
     spec = projection_spec(pose, W, W, 13.0 * W, S, 1400.0, 1600.0)
@@ -61,7 +61,7 @@ for enc in ("barf", "fourier"):
 # C3: hierarchical coarse (128) + fine (128 + 64), dense convention with per-ray depths, autograd backward
 W, SC, NF = 512, 128, 64
 m = opt = None; gc.collect(); torch.cuda.empty_cache()
-m = model(); opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+m = model(); opt = torch.optim.Adam(m.parameters(), lr=1e-4, fused=True)
 o, d, m44, _, _ = get_ray_values(20.0, 0.0, 0.0, np.array([0, 0, 1500.0]), W, W, 13.0 * W, dev)
 o, d = o.reshape(-1, 3).float().contiguous(), d.reshape(-1, 3).float().contiguous()
 tgt = torch.rand(W * W, device=dev); z = torch.linspace(1400.0, 1600.0, SC, device=dev)
@@ -106,7 +106,7 @@ for layers, width in ((4, 128), (8, 256)):
     md = dict(num_early_layers=layers, num_late_layers=0, num_filters=width, num_input_channels=3, num_output_channels=1,
               num_input_channels_views=0, use_bias=True, pos_enc="none", pos_enc_basis=5, act_func="relu", fourier_sigma=5,
               num_img=1, device=dev, precision="f16s8")
-    m = CPPN(md).to(dev); opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    m = CPPN(md).to(dev); opt = torch.optim.Adam(m.parameters(), lr=1e-4, fused=True)
     R, S = 5625, 300
     step_no = [0]
     def it():

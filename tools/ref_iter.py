@@ -26,7 +26,7 @@ if os.environ.get("AFX_VARIANT"):
     m._engine = Engine(width, layers, md["pos_enc"], 5 if md["pos_enc"] != "none" else 0, variant=os.environ["AFX_VARIANT"])
 if md["pos_enc"] == "barf":
     m.update_barf_alpha(2.5, "pts")
-opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+opt = torch.optim.Adam(m.parameters(), lr=1e-4, fused=os.environ.get("ADAM_FUSED", "1") != "0")      # (one multi-tensor kernel instead of the foreach sequence)
 R, S = 5625, 300
 n = [0]
 batches = RayBatchSampler(tab_o, tab_d, tab_p, tab_w, R, seed=0, prefetch=int(os.environ.get("PREFETCH", 16))) if os.environ.get("PREFETCH", "16") != "0" else None

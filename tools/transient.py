@@ -20,7 +20,7 @@ m = CPPN(md).to(dev)
 with torch.no_grad():
     m.output_linear[0].weight.mul_(4.0); m.output_linear[0].bias.fill_(-5.0)
 m.engine.max_workspace_bytes = 128 << 30
-opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+opt = torch.optim.Adam(m.parameters(), lr=1e-4, fused=True)
 W, SC, NF = 512, 128, 64
 o, d, m44, _, _ = get_ray_values(20.0, 0.0, 0.0, np.array([0, 0, 1500.0]), W, W, 13.0 * W, dev)
 pose = torch.from_numpy(m44[None]).to(dev)
