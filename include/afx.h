@@ -320,6 +320,10 @@ int afx_march_write(const afx_march_args* args, const int64_t* offsets, int32_t*
  * input_is_alpha != 0: `raw` already holds the caller's alpha_fn values.  offsets[R+1]; keep[n] in {0,1}; counts[r] = kept steps. */
 int afx_march_visibility(const float* raw, int32_t input_is_alpha, const float* t_starts, const float* t_ends, const int64_t* offsets,
                          int64_t n_rays, float early_stop_eps, float alpha_thre, uint8_t* keep, int32_t* counts, void* stream);
+/* counts[R] (afx_march_count / afx_march_visibility) -> offsets[R+1], the exclusive prefix sums both take back; optionally (non-null)
+ * group_offsets[R+1], the same over ceil(count / 32) - the offsets of the group-aligned copy afx_pack_groups lays out - and
+ * totals[2] = {samples, groups} for the caller's one host read.  One launch in place of the caller's zeros / cumsum sequence. */
+int afx_ray_offsets(const int32_t* counts, int64_t n_rays, int64_t* offsets, int64_t* group_offsets, int64_t* totals, void* stream);
 int afx_march_compact(const uint8_t* keep, const int64_t* offsets_in, const int64_t* offsets_out, int64_t n_rays,
                       const float* t_starts_in, const float* t_ends_in, int32_t* ray_indices_out, float* t_starts_out,
                       float* t_ends_out, void* stream);

@@ -93,6 +93,7 @@ _SIGS = {
     "afx_march_write": (C.c_int, [C.POINTER(MarchArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "afx_march_visibility": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
                                        C.c_void_p, C.c_void_p, C.c_void_p]),
+    "afx_ray_offsets": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "afx_march_compact": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "afx_sample_keys": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),

@@ -1221,6 +1221,13 @@ extern "C" int afx_march_compact(const uint8_t* keep, const int64_t* offsets_in,
   return AFX_OK;
 }
 
+extern "C" int afx_ray_offsets(const int32_t* counts, int64_t n_rays, int64_t* offsets, int64_t* group_offsets, int64_t* totals, void* stream) {
+  if (n_rays < 0 || !offsets || (n_rays > 0 && !counts)) return fail(AFX_E_INVALID, "afx_ray_offsets: null argument");
+  hipLaunchKernelGGL(k_ray_offsets, dim3(1), dim3(1024), 0, (hipStream_t)stream, counts, n_rays, offsets, group_offsets, totals);
+  HIPCHK(hipGetLastError());
+  return AFX_OK;
+}
+
 extern "C" int afx_sample_keys(const float* weights, int64_t n, const float* u, uint64_t seed, uint64_t stream_id, float* keys, void* stream) {
   if (n <= 0) return AFX_OK;
   if (!keys) return fail(AFX_E_INVALID, "afx_sample_keys: null keys");

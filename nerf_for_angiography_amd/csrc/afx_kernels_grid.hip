@@ -289,6 +289,38 @@ __global__ void __launch_bounds__(256) k_march_visibility(const float* raw, int 
   }
   if (lane == 0) counts[r] = c;
 }
+// counts[R] -> offsets[R+1] (exclusive prefix sums, int64), optionally the offsets of the group-aligned copy (ceil(count / 32) groups per
+// ray) and the two totals in one place for the host's single read.  One block: R is a batch of rays (5 625 in the reference), and the
+// torch sequence this replaces (zeros, cumsum = 2 rocprim launches, for the groups another 4) was a quarter of the launches of the
+// dispatch-bound grid iteration.
+__global__ void __launch_bounds__(1024) k_ray_offsets(const int32_t* counts, int64_t n_rays, int64_t* offsets, int64_t* group_offsets, int64_t* totals) {
+  __shared__ int64_t ps[1024], pg[1024];
+  const int t = threadIdx.x;
+  const int64_t per = (n_rays + 1023) / 1024, r0 = t * per, r1 = r0 + per < n_rays ? r0 + per : n_rays;
+  int64_t s = 0, g = 0;
+  for (int64_t r = r0; r < r1; ++r) { const int64_t c = counts[r]; s += c; g += (c + 31) >> 5; }
+  ps[t] = s; pg[t] = g;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {      // Hillis-Steele inclusive scan of the 1024 partial sums
+    const int64_t as = t >= d ? ps[t - d] : 0, ag = t >= d ? pg[t - d] : 0;
+    __syncthreads();
+    ps[t] += as; pg[t] += ag;
+    __syncthreads();
+  }
+  s = ps[t] - s; g = pg[t] - g;             // exclusive
+  for (int64_t r = r0; r < r1; ++r) {
+    const int64_t c = counts[r];
+    offsets[r] = s;
+    if (group_offsets) group_offsets[r] = g;
+    s += c; g += (c + 31) >> 5;
+  }
+  if (t == 1023) {
+    offsets[n_rays] = ps[1023];
+    if (group_offsets) group_offsets[n_rays] = pg[1023];
+    if (totals) { totals[0] = ps[1023]; totals[1] = pg[1023]; }
+  }
+}
+
 __global__ void __launch_bounds__(256) k_march_compact(const uint8_t* keep, const int64_t* offsets_in, const int64_t* offsets_out, int64_t n_rays,
                                                        const float* ts_in, const float* te_in, int32_t* ri_out, float* ts_out, float* te_out) {
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);

@@ -554,9 +554,10 @@ def march(origins, dirs, scene_aabb, near_plane, far_plane, step, grid_bits=None
     st = Engine._stream(dev)
     counts = torch.empty(o.shape[0], dtype=torch.int32, device=dev)
     _lib.check(lib.afx_march_count(C.byref(m), _ptr(counts), st), "afx_march_count")
-    offsets = torch.zeros(o.shape[0] + 1, dtype=torch.int64, device=dev)
-    torch.cumsum(counts, 0, out=offsets[1:])
-    n = int(offsets[-1])
+    offsets = torch.empty(o.shape[0] + 1, dtype=torch.int64, device=dev)
+    totals = torch.empty(2, dtype=torch.int64, device=dev)
+    _lib.check(lib.afx_ray_offsets(_ptr(counts), o.shape[0], _ptr(offsets), None, _ptr(totals), st), "afx_ray_offsets")
+    n = int(totals[0])      # the march's one host read
     ri = torch.empty(n, dtype=torch.int32, device=dev)
     ts, te = torch.empty(n, device=dev), torch.empty(n, device=dev)
     pts = torch.empty(n, 3, device=dev) if want_points else None
@@ -576,15 +577,11 @@ def march_visibility(raw, ts, te, offsets, early_stop_eps, alpha_thre, is_alpha=
     st = Engine._stream(dev)
     _lib.check(lib.afx_march_visibility(_ptr(raw), int(bool(is_alpha)), _ptr(ts), _ptr(te), _ptr(offsets), n_rays, float(early_stop_eps),
                                         float(alpha_thre), _ptr(keep), _ptr(counts), st), "afx_march_visibility")
-    off2 = torch.zeros(n_rays + 1, dtype=torch.int64, device=dev)
-    torch.cumsum(counts, 0, out=off2[1:])
-    goff = None
-    if return_offsets == "groups":      # + the group offsets of the group-aligned copy, fetched with the same host sync
-        goff = torch.zeros(n_rays + 1, dtype=torch.int64, device=dev)
-        torch.cumsum((counts + 31) // 32, 0, out=goff[1:])
-        n2, n_groups = torch.stack([off2[-1], goff[-1]]).tolist()
-    else:
-        n2 = int(off2[-1])
+    off2 = torch.empty(n_rays + 1, dtype=torch.int64, device=dev)
+    totals = torch.empty(2, dtype=torch.int64, device=dev)
+    goff = torch.empty(n_rays + 1, dtype=torch.int64, device=dev) if return_offsets == "groups" else None      # (the group-aligned copy's offsets)
+    _lib.check(lib.afx_ray_offsets(_ptr(counts), n_rays, _ptr(off2), _ptr(goff), _ptr(totals), st), "afx_ray_offsets")
+    n2, n_groups = totals.tolist()      # one host read for both
     ri2 = torch.empty(n2, dtype=torch.int32, device=dev)
     ts2, te2 = torch.empty(n2, device=dev), torch.empty(n2, device=dev)
     if n2 > 0:

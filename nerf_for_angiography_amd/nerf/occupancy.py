@@ -154,6 +154,23 @@ class OccupancyGrid(torch.nn.Module):
         return out
 
 
+_AABB_HOST = {}
+
+
+def _aabb_on_host(scene_aabb):
+    """The six floats of a scene box as host numbers.  The reference passes a DEVICE tensor on every iteration (run_nerf_acc.py:196,288);
+    reading it back each time is a host synchronisation per iteration, so the read is cached on (storage, version)."""
+    if not torch.is_tensor(scene_aabb) or not scene_aabb.is_cuda:
+        return [float(x) for x in torch.as_tensor(scene_aabb).flatten().tolist()]
+    key = (scene_aabb.data_ptr(), scene_aabb._version, scene_aabb.device.index)
+    hit = _AABB_HOST.get(key)
+    if hit is None:
+        if len(_AABB_HOST) > 64:
+            _AABB_HOST.clear()
+        hit = _AABB_HOST[key] = [float(x) for x in scene_aabb.flatten().tolist()]
+    return hit
+
+
 @torch.no_grad()
 def ray_marching(rays_o, rays_d, scene_aabb=None, grid=None, alpha_fn=None, near_plane=None, far_plane=None,
                  early_stop_eps=1e-4, alpha_thre=0.0, render_step_size=1e-3, raw_fn=None, return_packed=False):
@@ -163,7 +180,7 @@ def ray_marching(rays_o, rays_d, scene_aabb=None, grid=None, alpha_fn=None, near
     kernel, so nothing but the MLP launch sits between the two."""
     if not rays_o.is_cuda:
         raise AfxError("ray_marching: rays must live on a GPU; there is no CPU fallback")
-    aabb = None if scene_aabb is None else [float(x) for x in torch.as_tensor(scene_aabb).flatten().tolist()]
+    aabb = None if scene_aabb is None else _aabb_on_host(scene_aabb)
     bits = grid.bits if grid is not None else None
     ri, ts, te, pts, offsets = _engine.march(rays_o, rays_d, aabb, near_plane, far_plane, render_step_size, grid_bits=bits,
                                              grid_aabb=None if grid is None else grid._aabb_host,
