@@ -409,14 +409,17 @@ static int launch_chain_f(afx_ctx* c, int prec, bool bwd, const ChainArgs& a, si
 
 static int launch_chain(afx_ctx* c, int prec, bool bwd, const ChainArgs& a, hipStream_t st, int phase = 0) {
   const int F = c->d.width, N = c->d.n_hidden;
-  size_t lds = (size_t)a.small_bytes_pad + (size_t)(is_bf16(prec) ? chain_ring(bwd) : 2) * a.slot_bytes;
+  const bool occ2 = chain_occ2(c->nt, phase);      // backward half at widths <= 128: two workgroups per CU, two-tile steps
+  const size_t slot = occ2 ? chain_slot_bytes(c->nt, nk0_of(c), true, false, 2) : a.slot_bytes;
+  size_t lds = (size_t)a.small_bytes_pad + (size_t)(is_bf16(prec) ? chain_ring(bwd) : 2) * slot;
   const int ncg = (is_bf16(prec) && (bwd || prec == AFX_PREC_BF16 || is_f16(prec))) ? 2 : 1;
   if (bwd) lds += (size_t)(N + 1) * ((c->nt + 1) / 2) * ncg * 256 * 4 + 256;   // ReLU masks + per-group optical depths
   if (lds > 160 * 1024) return fail(AFX_E_INVALID, "model needs %zu B of LDS (> 160 KiB)", lds);
   const int tiles = a.tile1 - a.tile0;
   if (tiles <= 0) return AFX_OK;
   if (int rc = check_dev(c, "afx chain launch")) return rc;
-  const int grid = (tiles < c->n_cu || !a.persistent) ? tiles : c->n_cu;    // persistent: one workgroup per CU loops over tiles
+  const int wgs = occ2 ? 2 * c->n_cu : c->n_cu;
+  const int grid = (tiles < wgs || !a.persistent) ? tiles : wgs;    // persistent: one workgroup per CU (occ2: two) loops over tiles
   if (F == 64) return launch_chain_f<64>(c, prec, bwd, a, lds, grid, st, phase);
   if (F == 128) return launch_chain_f<128>(c, prec, bwd, a, lds, grid, st, phase);
   return launch_chain_f<256>(c, prec, bwd, a, lds, grid, st, phase);

@@ -15,12 +15,22 @@ constexpr int GROUP = 32;            // samples per wave column group; s_pad is 
 // ring of one-tile steps, requested 3 steps ahead, measured 5 ms slower per 512^2x128 step: twice the barriers).
 // tiles per step: 4 in the forward-only kernels and, at width 128 (a layer is 4 tiles, its slabs 32 KiB), also in the backward kernel -
 // one barrier per layer; at width 256 the backward kernel's ReLU masks leave LDS room for 2-tile steps only
-constexpr int chain_tps(int nt, bool bwd, bool x3) { return (nt >= 4 && !x3 && (!bwd || nt == 4)) ? 4 : (nt >= 2 ? 2 : 1); }
+// PHASE 2 (the backward half of the split training step) at widths <= 128: TWO workgroups per CU (AFX_P2_OCC2, default on).  At those widths
+// a tile is 8 MFMAs against an epilogue of the same length as at width 256, so a lone workgroup - whose two waves per SIMD run in lockstep
+// behind the step barrier - leaves the matrix pipe idle most of the time; a second, unsynchronised workgroup fills it.  That needs <= 128
+// VGPRs per wave (the backward half fits: no forward activations, no in-kernel group sums) and <= 80 KB of LDS: two-tile steps.
+#ifndef AFX_P2_OCC2
+#define AFX_P2_OCC2 1
+#endif
+constexpr bool chain_occ2(int nt, int phase) { return AFX_P2_OCC2 && phase == 2 && nt <= 4; }
+constexpr int chain_tps(int nt, bool bwd, bool x3, int phase = 0) {
+  return chain_occ2(nt, phase) ? (nt >= 2 ? 2 : 1) : ((nt >= 4 && !x3 && (!bwd || nt == 4)) ? 4 : (nt >= 2 ? 2 : 1));
+}
 constexpr int chain_ring(bool bwd) { return 2; }
 constexpr uint32_t chain_slab0_bytes(int nk0) { return ((uint32_t)nk0 * 2048u + 4095u) / 4096u * 4096u; }
-constexpr uint32_t chain_slot_bytes(int nt, int nk0, bool bwd, bool x3) {
-  const uint32_t s0 = (uint32_t)chain_tps(nt, bwd, x3) * chain_slab0_bytes(nk0);
-  const uint32_t sh = (uint32_t)chain_tps(nt, bwd, x3) * (uint32_t)nt * 2048u * (x3 ? 2u : 1u);
+constexpr uint32_t chain_slot_bytes(int nt, int nk0, bool bwd, bool x3, int phase = 0) {
+  const uint32_t s0 = phase == 2 ? 0u : (uint32_t)chain_tps(nt, bwd, x3, phase) * chain_slab0_bytes(nk0);      // (the backward half streams no first-layer slab)
+  const uint32_t sh = (uint32_t)chain_tps(nt, bwd, x3, phase) * (uint32_t)nt * 2048u * (x3 ? 2u : 1u);
   return s0 > sh ? s0 : sh;
 }
 

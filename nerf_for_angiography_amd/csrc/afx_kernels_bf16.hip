@@ -267,7 +267,7 @@ template <int K> __device__ __forceinline__ void lds_wait_frag(u32x4& r) {
 // ACTV = 1: the forward-only kernels for tanh / sine models (a.act): the activation is applied to the accumulator in the epilogue instead of
 // the packed-ReLU steps.  Separate instantiations, so that the ReLU kernels stay exactly the code they were.
 template <int F, bool X3, bool ENC, bool BWD, int NW, bool SG = false, bool H16 = false, bool S8 = false, int PHASE = 0, int ACTV = 0>
-__global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs a) {
+__global__ void __launch_bounds__(64 * NW, chain_occ2(F / 32, PHASE) ? 4 : NW / 4) k_chain_bf16(const ChainArgs a) {
   static_assert(PHASE == 0 || (S8 && PHASE <= 2), "split phases: the 8-bit-stash kernel");
   static_assert(ACTV == 0 || (!BWD && !ENC), "tanh / sine: forward-only kernels without an input encoding");
   constexpr bool P1 = PHASE == 1, P2 = PHASE == 2;
@@ -293,7 +293,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
   uint64_t ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   uint64_t tlast = __builtin_amdgcn_s_memtime();
 #endif
-  constexpr int TPS = chain_tps(NT, BWD, X3);
+  constexpr int TPS = chain_tps(NT, BWD, X3, PHASE);
   constexpr int RING = chain_ring(BWD);               // LDS slots of the weight ring
   constexpr int PD = RING - 1;                        // a step's slabs are requested PD steps ahead
   static_assert(!SG || PD == 1, "SG marks its store-less steps for PD = 1 only");
@@ -303,7 +303,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_bf16(const ChainArgs 
   constexpr uint32_t SLAB0 = chain_slab0_bytes(NK0);                  // first-layer slab: NK0 x (hi,lo) KiB, zero-padded
   constexpr uint32_t SLABT = NT * 2048u;                              // one hidden slab part (hi or lo)
   constexpr uint32_t STEP0 = TPS * SLAB0, STEPH = TPS * SLABT;        // bytes one step streams (X3: STEPH hi + STEPH lo)
-  constexpr uint32_t SLOT = chain_slot_bytes(NT, NK0, BWD, X3);
+  constexpr uint32_t SLOT = chain_slot_bytes(NT, NK0, BWD, X3, PHASE);
   constexpr int PIECES0 = STEP0 / (NW * 1024u), PIECESH = STEPH / (NW * 1024u);      // LDS-DMA instructions per wave and step
   constexpr int SPS = (S8 ? 1 : 2) * NCG * TPS;                       // stash stores per wave and step (backward kernel)
 
