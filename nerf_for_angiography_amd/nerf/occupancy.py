@@ -27,6 +27,8 @@ packed training step (`render.train_step_packed_mse`: the reference's positions 
 backward in one pass)."""
 from __future__ import annotations
 
+import weakref
+
 import torch
 
 from .. import engine as _engine
@@ -154,21 +156,21 @@ class OccupancyGrid(torch.nn.Module):
         return out
 
 
-_AABB_HOST = {}
+_AABB_HOST = []      # [(weakref to the tensor, version, six floats)]
 
 
 def _aabb_on_host(scene_aabb):
-    """The six floats of a scene box as host numbers.  The reference passes a DEVICE tensor on every iteration (run_nerf_acc.py:196,288);
-    reading it back each time is a host synchronisation per iteration, so the read is cached on (storage, version)."""
+    """The six floats of a scene box as host numbers.  The reference passes the same DEVICE tensor on every iteration (run_nerf_acc.py:196,288);
+    reading it back each time is a host synchronisation per iteration, so the read is remembered for that tensor OBJECT (weak reference) at
+    that version - a different tensor, or the same one after an in-place write, is read again."""
     if not torch.is_tensor(scene_aabb) or not scene_aabb.is_cuda:
         return [float(x) for x in torch.as_tensor(scene_aabb).flatten().tolist()]
-    key = (scene_aabb.data_ptr(), scene_aabb._version, scene_aabb.device.index)
-    hit = _AABB_HOST.get(key)
-    if hit is None:
-        if len(_AABB_HOST) > 64:
-            _AABB_HOST.clear()
-        hit = _AABB_HOST[key] = [float(x) for x in scene_aabb.flatten().tolist()]
-    return hit
+    for ref, version, vals in _AABB_HOST:
+        if ref() is scene_aabb and version == scene_aabb._version:
+            return vals
+    vals = [float(x) for x in scene_aabb.flatten().tolist()]
+    _AABB_HOST[:] = [e for e in _AABB_HOST if e[0]() is not None and e[0]() is not scene_aabb][-7:] + [(weakref.ref(scene_aabb), scene_aabb._version, vals)]
+    return vals
 
 
 @torch.no_grad()

@@ -893,3 +893,22 @@ def test_prepared_weight_cache_follows_optimizer_steps(fused):
         fresh.load_state_dict(m.state_dict())
         want = render_rays(fresh, o, d, 64, 1400.0, 1600.0, mode="acc").rgb_map
     assert not torch.equal(before, after) and torch.equal(after, want)
+
+
+def test_scene_box_read_back_is_cached_per_tensor_and_version():
+    """ray_marching takes the scene box as a DEVICE tensor (run_nerf_acc.py:196,288); the read-back is remembered for that tensor object and
+    version (one host synchronisation less per iteration), so an in-place change and a different tensor must both be seen."""
+    from nerf_for_angiography_amd.nerf.occupancy import ray_marching
+    o, d, _ = _ref_iteration_problem(64, seed=3)
+    o, d = o.to(DEV), d.to(DEV)
+    box = torch.tensor([-100.0, -100, -100, 100, 100, 100], device=DEV)
+    n = lambda b: ray_marching(o, d, scene_aabb=b, near_plane=1400.0, far_plane=1600.0, render_step_size=1.0)[0].numel()
+    n_full = n(box)
+    assert n(box) == n_full and 64 * 150 < n_full <= 64 * 201
+    box.mul_(0.5)                                     # same tensor, new version
+    n_half = n(box)
+    assert 0 < n_half < 0.6 * n_full
+    del box
+    other = torch.tensor([-25.0, -25, -25, 25, 25, 25], device=DEV)      # (may reuse the freed tensor's address)
+    assert 0 < n(other) < 0.6 * n_half
+    assert n([-100.0, -100, -100, 100, 100, 100]) == n_full
