@@ -328,6 +328,27 @@ int afx_march_compact(const uint8_t* keep, const int64_t* offsets_in, const int6
                       const float* t_starts_in, const float* t_ends_in, int32_t* ray_indices_out, float* t_starts_out,
                       float* t_ends_out, void* stream);
 
+/* The whole grid iteration of nerf/run_nerf_acc.py:284-306 in ONE call: afx_march_count / afx_ray_offsets / afx_march_write (candidates),
+ * afx_mlp_infer at the candidates' mid-points + afx_march_visibility (the reference's alpha_fn + nerfacc's render_visibility),
+ * afx_march_compact / afx_pack_groups, afx_train_step_packed_mse - the same entry points in the same order, so the results are those of
+ * the call-by-call sequence bit for bit.  (At the reference's batch the GPU is busy for 0.27 ms of an iteration; the ~30 launches cost more
+ * when a Python loop issues them.)  Two host read-backs inside (sizes are data), so the call is NOT graph-capturable.  Every array
+ * between the steps lives in `workspace`; when it is too small the call returns AFX_E_WORKSPACE with `workspace_needed` set (nothing the
+ * caller owns has been written) - grow and call again.  n_kept == 0 on return: no sample survived, pixel / grad_flat untouched (the
+ * reference skips the optimizer step, :293). */
+typedef struct afx_march_train_args {
+  afx_march_args march;             /* rays, scene box, planes, step, occupancy bits: as for afx_march_count */
+  float early_stop_eps, alpha_thre; /* render_visibility thresholds (run_nerf_acc.py:68-70) */
+  const float* target;              /* [R] */
+  float inv_n;                      /* 1 / rays of the global batch */
+  float* pixel;                     /* [R] out */
+  float* grad_flat;                 /* += dL/dparams */
+  void* workspace; size_t workspace_bytes;
+  int64_t n_candidates, n_kept, n_groups;      /* out */
+  size_t workspace_needed;                     /* out, with AFX_E_WORKSPACE */
+} afx_march_train_args;
+int afx_march_train_step_mse(afx_ctx* ctx, int prec, const void* prepared, afx_march_train_args* args, void* stream);
+
 /* Indices of the k largest of keys[n] (ties: lowest index first), written in ASCENDING INDEX order - the selection step of the
  * weighted ray sampler (the batch of nerf/nerf_helpers.py:137-150 is a set; its order carries no meaning).  Radix select:
  * three histogram passes + a counted compaction, deterministic, no full sort.  workspace: afx_topk_workspace_bytes(n) bytes

@@ -42,6 +42,12 @@ class MarchArgs(C.Structure):
                 ("far_plane", C.c_float), ("step", C.c_float), ("grid_bits", C.c_void_p), ("grid", GridDesc)]
 
 
+class MarchTrainArgs(C.Structure):
+    _fields_ = [("march", MarchArgs), ("early_stop_eps", C.c_float), ("alpha_thre", C.c_float), ("target", C.c_void_p), ("inv_n", C.c_float),
+                ("pixel", C.c_void_p), ("grad_flat", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+                ("n_candidates", C.c_int64), ("n_kept", C.c_int64), ("n_groups", C.c_int64), ("workspace_needed", C.c_size_t)]
+
+
 _SIGS = {
     "afx_create": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(C.c_void_p)]),
     "afx_destroy": (None, [C.c_void_p]),
@@ -93,6 +99,7 @@ _SIGS = {
     "afx_march_write": (C.c_int, [C.POINTER(MarchArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "afx_march_visibility": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
                                        C.c_void_p, C.c_void_p, C.c_void_p]),
+    "afx_march_train_step_mse": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(MarchTrainArgs), C.c_void_p]),
     "afx_ray_offsets": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "afx_march_compact": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -1330,3 +1330,73 @@ extern "C" int afx_philox_uniform(uint64_t seed, uint64_t stream_id, int64_t n, 
   HIPCHK(hipGetLastError());
   return AFX_OK;
 }
+
+// ---- the reference's grid iteration in ONE call (nerf/run_nerf_acc.py:284-306): march -> alpha pass -> visibility -> packed training step.
+// The same entry points, in the same order, that the Python mirror calls one by one (occupancy.ray_marching, render.train_step_packed_mse) -
+// composed here because at the reference's batch the GPU work of an iteration is 0.27 ms and ~30 launches issued from Python are not.
+extern "C" int afx_march_train_step_mse(afx_ctx* c, int prec, const void* prepared, afx_march_train_args* t, void* stream) {
+  if (!c || !prepared || !t) return fail(AFX_E_INVALID, "afx_march_train_step_mse: null argument");
+  t->n_candidates = t->n_kept = t->n_groups = 0; t->workspace_needed = 0;
+  const afx_march_args& m = t->march;
+  const int64_t R = m.n_rays;
+  if (R <= 0) return AFX_OK;
+  if (!m.origins || !m.dirs || !t->target || !t->pixel || !t->grad_flat || !t->workspace)
+    return fail(AFX_E_INVALID, "afx_march_train_step_mse: null argument");
+  if (prec != AFX_PREC_F16S8 || !c->small_in_kernel) return fail(AFX_E_INVALID, "afx_march_train_step_mse: AFX_PREC_F16S8 only");
+  if (int rc = check_dev(c, "afx_march_train_step_mse")) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  char* ws = (char*)t->workspace;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t at = off; off += rup64(bytes, 256); return at; };
+  auto too_small = [&](size_t more) {
+    t->workspace_needed = off + more + 4096;
+    return fail(AFX_E_WORKSPACE, "afx_march_train_step_mse: workspace %zu < %zu bytes", t->workspace_bytes, t->workspace_needed);
+  };
+  // 1. candidates: steps of the march whose cell is occupied
+  const size_t o_counts = take((size_t)R * 4), o_offsets = take((size_t)(R + 1) * 8), o_totals = take(4 * 8);
+  const size_t o_counts2 = take((size_t)R * 4), o_off2 = take((size_t)(R + 1) * 8), o_goff = take((size_t)(R + 1) * 8);
+  if (off > t->workspace_bytes) return too_small(0);
+  int32_t* counts = (int32_t*)(ws + o_counts);
+  int64_t* offsets = (int64_t*)(ws + o_offsets);
+  int64_t* totals = (int64_t*)(ws + o_totals);
+  int rc;
+  if ((rc = afx_march_count(&m, counts, stream))) return rc;
+  if ((rc = afx_ray_offsets(counts, R, offsets, nullptr, totals, stream))) return rc;
+  int64_t h[4] = {0, 0, 0, 0};
+  HIPCHK(hipMemcpyAsync(h, totals, 16, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));      // (sizes are data: the candidate count)
+  const int64_t n = h[0];
+  t->n_candidates = n;
+  if (n == 0) return AFX_OK;
+  if (n > ((int64_t)1 << 31) - 256) return fail(AFX_E_INVALID, "afx_march_train_step_mse: %lld candidates", (long long)n);
+  const size_t o_ri = take((size_t)n * 4), o_ts = take((size_t)n * 4), o_te = take((size_t)n * 4), o_pts = take((size_t)n * 12),
+               o_raw = take((size_t)n * 4), o_keep = take((size_t)n);
+  if (off > t->workspace_bytes) return too_small(0);
+  int32_t* ri = (int32_t*)(ws + o_ri);
+  float *ts = (float*)(ws + o_ts), *te = (float*)(ws + o_te), *pts = (float*)(ws + o_pts), *raw = (float*)(ws + o_raw);
+  uint8_t* keep = (uint8_t*)(ws + o_keep);
+  if ((rc = afx_march_write(&m, offsets, ri, ts, te, pts, stream))) return rc;
+  // 2. alpha pass (alpha_fn, nerf_helpers_acc.py:11-25) + render_visibility
+  if ((rc = afx_mlp_infer(c, prec, prepared, pts, n, raw, 0, stream))) return rc;
+  int32_t* counts2 = (int32_t*)(ws + o_counts2);
+  int64_t *off2 = (int64_t*)(ws + o_off2), *goff = (int64_t*)(ws + o_goff);
+  if ((rc = afx_march_visibility(raw, 0, ts, te, offsets, R, t->early_stop_eps, t->alpha_thre, keep, counts2, stream))) return rc;
+  if ((rc = afx_ray_offsets(counts2, R, off2, goff, totals + 2, stream))) return rc;
+  HIPCHK(hipMemcpyAsync(h + 2, totals + 2, 16, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));      // (the kept count and the group count)
+  const int64_t n2 = h[2], ng = h[3];
+  t->n_kept = n2; t->n_groups = ng;
+  if (n2 == 0) return AFX_OK;            // nothing survived: the reference skips the step (:293)
+  // 3. compaction, group-aligned copy, fused training step
+  const size_t o_ri2 = take((size_t)n2 * 4), o_ts2 = take((size_t)n2 * 4), o_te2 = take((size_t)n2 * 4);
+  const size_t o_tsp = take((size_t)ng * 32 * 4), o_tep = take((size_t)ng * 32 * 4), o_gray = take((size_t)ng * 4);
+  const size_t step_ws = (size_t)afx_query(c, AFX_Q_BWD_WORKSPACE_FULL, 0, ng * 32, prec) + 4 * (size_t)(R + ng) + 1024;
+  if (off + step_ws > t->workspace_bytes) return too_small(step_ws);
+  int32_t* ri2 = (int32_t*)(ws + o_ri2);
+  float *ts2 = (float*)(ws + o_ts2), *te2 = (float*)(ws + o_te2), *tsp = (float*)(ws + o_tsp), *tep = (float*)(ws + o_tep);
+  int32_t* gray = (int32_t*)(ws + o_gray);
+  if ((rc = afx_march_compact(keep, offsets, off2, R, ts, te, ri2, ts2, te2, stream))) return rc;
+  if ((rc = afx_pack_groups(off2, goff, R, ts2, te2, tsp, tep, gray, stream))) return rc;
+  return afx_train_step_packed_mse(c, prec, prepared, m.origins, m.dirs, R, goff, gray, ng, tsp, tep, t->target, t->inv_n, t->pixel, t->grad_flat,
+                                   ws + off, t->workspace_bytes - off, stream);
+}

@@ -288,6 +288,35 @@ class Engine:
                                                       _ptr(grad_flat), _ptr(ws), ws.numel(), self._stream(dev)), "afx_train_step_packed_mse")
         return pixel
 
+    def march_train_step_mse(self, prepared, origins, dirs, target, inv_n: float, grad_flat, prec: str, scene_aabb, near_plane, far_plane,
+                             step: float, early_stop_eps: float, alpha_thre: float, grid_bits=None, grid_aabb=None, grid_res=None):
+        """afx_march_train_step_mse: the reference's grid iteration (march, alpha pass, visibility, packed training step) in one call.
+        Returns (pixels [n_rays], n_candidates, n_kept); n_kept == 0: nothing survived, pixels / grad_flat untouched."""
+        dev = prepared.device
+        o, d, target = _f32(origins, "origins", dev), _f32(dirs, "dirs", dev), _f32(target, "target", dev)
+        n_rays = o.shape[0]
+        if tuple(o.shape) != (n_rays, 3) or tuple(d.shape) != (n_rays, 3) or target.numel() != n_rays:
+            raise ValueError("march_train_step_mse: origins/dirs [n_rays,3] and target [n_rays] expected")
+        pixel = torch.empty(n_rays, dtype=torch.float32, device=dev)
+        a = _lib.MarchTrainArgs()
+        _fill_march_args(a.march, o, d, scene_aabb, near_plane, far_plane, step, grid_bits, grid_aabb, grid_res)
+        a.early_stop_eps, a.alpha_thre, a.inv_n = float(early_stop_eps), float(alpha_thre), float(inv_n)
+        a.target, a.pixel, a.grad_flat = target.data_ptr(), pixel.data_ptr(), grad_flat.data_ptr()
+        need = max(64 << 20, self._ws.numel() if self._ws is not None and self._ws.device == dev else 0)
+        for _ in range(4):
+            if need > self.max_workspace_bytes:
+                raise AfxError(f"march_train_step_mse: the iteration needs a {need >> 20} MiB workspace (max_workspace_bytes = "
+                               f"{self.max_workspace_bytes >> 20} MiB)")
+            ws = self._workspace(need, dev)
+            a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+            rc = self.lib.afx_march_train_step_mse(self.h, _lib.PREC[prec], _ptr(prepared), C.byref(a), self._stream(dev))
+            if rc == -2 and a.workspace_needed > ws.numel():      # AFX_E_WORKSPACE: sizes are data - grow (25 % head-room) and run the iteration again
+                need = int(a.workspace_needed)
+                continue
+            self._check(rc, "afx_march_train_step_mse")
+            return pixel, int(a.n_candidates), int(a.n_kept)
+        raise AfxError("march_train_step_mse: the workspace did not converge")
+
     def hier_train_step_mse(self, prepared, spec: RenderSpec, n_fine: int, u, target, inv_n: float, grad_flat, prec: str, want_z_all=True):
         """afx_hier_train_step_mse: hierarchical step with coarse re-use; `spec` carries the rays and the COARSE depths (mode 'dense').
         Returns (pixels [R], merged depths [R, S + n_fine] | None)."""
@@ -529,15 +558,7 @@ def grid_pack(roi_aabb, resolution, binary_u8, bits):
     _lib.check(lib.afx_grid_pack(C.byref(g), _ptr(binary_u8), _ptr(bits), Engine._stream(binary_u8.device)), "afx_grid_pack")
 
 
-def march(origins, dirs, scene_aabb, near_plane, far_plane, step, grid_bits=None, grid_aabb=None, grid_res=None, want_points=True):
-    """Grid-skipping fixed-step march -> packed (ray_indices int32 [n], t_starts [n], t_ends [n], mid-points [n,3] | None,
-    offsets int64 [R+1])."""
-    lib = _lib.load()
-    dev = origins.device
-    if dev.type != "cuda":
-        raise AfxError("march: rays must live on a GPU; there is no CPU fallback")
-    o, d = _f32(origins, "origins", dev), _f32(dirs, "dirs", dev)
-    m = _lib.MarchArgs()
+def _fill_march_args(m, o, d, scene_aabb, near_plane, far_plane, step, grid_bits, grid_aabb, grid_res):
     m.origins, m.dirs, m.n_rays = o.data_ptr(), d.data_ptr(), o.shape[0]
     if scene_aabb is not None:
         m.has_aabb = 1
@@ -551,6 +572,18 @@ def march(origins, dirs, scene_aabb, near_plane, far_plane, step, grid_bits=None
     if grid_bits is not None:
         m.grid_bits = grid_bits.data_ptr()
         m.grid = _grid_desc(grid_aabb, grid_res)
+
+
+def march(origins, dirs, scene_aabb, near_plane, far_plane, step, grid_bits=None, grid_aabb=None, grid_res=None, want_points=True):
+    """Grid-skipping fixed-step march -> packed (ray_indices int32 [n], t_starts [n], t_ends [n], mid-points [n,3] | None,
+    offsets int64 [R+1])."""
+    lib = _lib.load()
+    dev = origins.device
+    if dev.type != "cuda":
+        raise AfxError("march: rays must live on a GPU; there is no CPU fallback")
+    o, d = _f32(origins, "origins", dev), _f32(dirs, "dirs", dev)
+    m = _lib.MarchArgs()
+    _fill_march_args(m, o, d, scene_aabb, near_plane, far_plane, step, grid_bits, grid_aabb, grid_res)
     st = Engine._stream(dev)
     counts = torch.empty(o.shape[0], dtype=torch.int32, device=dev)
     _lib.check(lib.afx_march_count(C.byref(m), _ptr(counts), st), "afx_march_count")

@@ -10,7 +10,7 @@ Three iteration bodies (--march): `dense` (default) is ONE fused launch per ray 
 MLP -> Beer-Lambert -> MSE -> backward; render + autograd with --precision f32); `grid` is the reference's own body,
 run_nerf_acc.py:284-306 - acc_update_n_step for both grids, acc_ray_marching with the occupancy grid (HIP march / visibility
 kernels, nerf/occupancy.py), then positions / get_predictions / acc_render_volume_density / mse_loss / backward as ONE fused pass
-over the march's packed samples (`train_step_packed_mse`; f16s8); `grid_ops` is the same body call for call through
+over the march's packed samples, march included, in one library call (`march_train_step_mse`; f16s8); `grid_ops` is the same body call for call through
 the mirrored functions (also what `grid` does at the other precisions).
 The training rays live on the GPU: one table (origins, directions, pixel, weight) built once, and every iteration's
 batch is drawn there (weighted sampling without replacement, `engine.sample_rays`); --host_sampler restores the
@@ -33,7 +33,7 @@ from ..engine import RenderSpec
 from ..model.CPPN import CPPN
 from ..phantomdata import dataset as ds
 from .. import engine as _engine
-from ..render import render_rays, train_step_mse, train_step_packed_mse
+from ..render import render_rays, train_step_mse, march_train_step_mse
 from .nerf_helpers import sample_pixel_rays, get_predictions
 from .nerf_helpers_acc import acc_ray_marching, acc_render_volume_density, acc_update_n_step
 from .occupancy import OccupancyGrid, ContractionType
@@ -189,22 +189,29 @@ def main(argv=None):
                 vessel_acc_grid.train()
                 acc_grid = acc_update_n_step(acc_grid, coarse_model, n_iter, occ_thre=alpha_thre)
                 vessel_acc_grid = acc_update_n_step(vessel_acc_grid, coarse_model, n_iter, occ_thre=vessel_alpha_thre)
-                marched = acc_ray_marching(coarse_model, acc_grid, scene_aabb, batch_origins, batch_directions,
-                                           depth_samples_per_ray_coarse, near_thresh, far_thresh, early_stop_eps, alpha_thre,
-                                           return_packed=packed_step)
-                ray_indices, t_starts, t_ends = marched[:3]
-            if len(ray_indices) > 0 and packed_step:
-                # :289-306 in one fused pass over the packed samples (forward half, per-ray product, backward half; MLP evaluated once)
-                loss_coarse, pred = train_step_packed_mse(coarse_model, batch_origins, batch_directions, marched[3], batch_pix_vals)
-                n_marched += int(len(ray_indices))
-            elif len(ray_indices) > 0:
-                positions = batch_origins[ray_indices.long()] + batch_directions[ray_indices.long()] * (t_starts + t_ends) / 2.0
-                predictions = get_predictions(coarse_model, positions, batch_size)
-                pred, _ = acc_render_volume_density(predictions, ray_indices, t_starts, t_ends, img_sample_size,
-                                                    depth_samples_per_ray_coarse)
-                loss_coarse = torch.nn.functional.mse_loss(pred, batch_pix_vals)
-                loss_coarse.backward()
-                n_marched += int(len(ray_indices))
+            if packed_step:
+                # :287-306 - march, alpha pass, visibility and the fused packed step - as ONE library call (the entry points of the
+                # operator branch below, in the same order: ~30 launches that a Python loop issues slower than the GPU runs them)
+                loss_k, pred_k, n_kept = march_train_step_mse(coarse_model, acc_grid, scene_aabb, batch_origins, batch_directions,
+                                                              depth_samples_per_ray_coarse, near_thresh, far_thresh, early_stop_eps,
+                                                              alpha_thre, batch_pix_vals)
+                ray_indices = range(n_kept)      # (only its length is used below: the reference steps when the march kept samples)
+                if n_kept:
+                    loss_coarse, pred = loss_k, pred_k
+                    n_marched += n_kept
+            else:
+                with torch.no_grad():
+                    ray_indices, t_starts, t_ends = acc_ray_marching(coarse_model, acc_grid, scene_aabb, batch_origins, batch_directions,
+                                                                     depth_samples_per_ray_coarse, near_thresh, far_thresh, early_stop_eps,
+                                                                     alpha_thre)
+                if len(ray_indices) > 0:
+                    positions = batch_origins[ray_indices.long()] + batch_directions[ray_indices.long()] * (t_starts + t_ends) / 2.0
+                    predictions = get_predictions(coarse_model, positions, batch_size)
+                    pred, _ = acc_render_volume_density(predictions, ray_indices, t_starts, t_ends, img_sample_size,
+                                                        depth_samples_per_ray_coarse)
+                    loss_coarse = torch.nn.functional.mse_loss(pred, batch_pix_vals)
+                    loss_coarse.backward()
+                    n_marched += int(len(ray_indices))
         elif args.precision == 'f32':
             pred = render_rays(coarse_model, batch_origins, batch_directions, depth_samples_per_ray_coarse, near_thresh,
                                far_thresh, mode='acc').rgb_map

@@ -206,6 +206,44 @@ def train_step_packed_mse(model, ray_origins, ray_directions, packed, target: to
     return loss, pixel
 
 
+def march_train_step_mse(model, grid, scene_aabb, ray_origins, ray_directions, depth_samples_per_ray: int, near_thresh: float, far_thresh: float,
+                         early_stop_eps: float, alpha_thre: float, target: torch.Tensor, n_global: Optional[int] = None):
+    """The reference's whole grid iteration - acc_ray_marching (march through the occupancy grid, alpha_fn pass, render_visibility) followed by the
+    body (positions, get_predictions, acc_render_volume_density, mse_loss, backward; nerf/run_nerf_acc.py:284-306) - as ONE library call
+    (afx_march_train_step_mse): what `nerf_helpers_acc.acc_ray_marching(..., return_packed=True)` + `train_step_packed_mse` do, entry point for
+    entry point and bit for bit, without a Python round trip per launch.  `grid`: nerf.occupancy.OccupancyGrid or None.  f16s8.
+    Gradients are ACCUMULATED into `.grad`.  Returns (loss, pixels[n_rays], n_kept) - (None, None, 0) when no sample survived the march (the
+    reference then skips the optimizer step, :293)."""
+    _check_model(model)
+    if model.precision != "f16s8":
+        raise NotImplementedError("march_train_step_mse: precision 'f16s8' (other precisions: acc_ray_marching + the operator sequence)")
+    from .nerf.occupancy import _aabb_on_host
+    n_rays = ray_origins.shape[0]
+    n = _global_rays(n_rays, n_global, model.flat_params.device)
+    flat_grad = torch.zeros(model.engine.param_count, dtype=torch.float32, device=model.flat_params.device)
+    coef_grad = model._coef_grad_buffer()
+    step = (float(far_thresh) - float(near_thresh)) / int(depth_samples_per_ray)
+    with model.engine.encoding_grad(model.flat_params, coef_grad):
+        pixel, _, n_kept = model.engine.march_train_step_mse(
+            model._prepared(), ray_origins, ray_directions, target, 1.0 / n, flat_grad, model.precision,
+            None if scene_aabb is None else _aabb_on_host(scene_aabb), near_thresh, far_thresh, step, early_stop_eps, alpha_thre,
+            grid_bits=None if grid is None else grid.bits, grid_aabb=None if grid is None else grid._aabb_host,
+            grid_res=None if grid is None else grid._res_host)
+    if n_kept == 0:
+        return None, None, 0
+    if _grad_hook is not None:
+        _grad_hook(flat_grad)
+        if coef_grad is not None:
+            _grad_hook(coef_grad)
+    for p, g in zip(model._fn_params(), model._fn_grads(flat_grad, coef_grad)):
+        if p.grad is None:
+            p.grad = g
+        else:
+            p.grad.add_(g)
+    loss = torch.nn.functional.mse_loss(pixel, target) if n == n_rays else ((pixel - target) ** 2).sum() / n
+    return loss, pixel, n_kept
+
+
 def hierarchical_train_step_mse(model, ray_origins, ray_directions, depth_values, depth_samples_per_ray_fine: int,
                                 target: torch.Tensor, u: Optional[torch.Tensor] = None, n_global: Optional[int] = None,
                                 fine_model=None, reuse_coarse: bool = True):

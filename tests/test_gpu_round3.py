@@ -912,3 +912,45 @@ def test_scene_box_read_back_is_cached_per_tensor_and_version():
     other = torch.tensor([-25.0, -25, -25, 25, 25, 25], device=DEV)      # (may reuse the freed tensor's address)
     assert 0 < n(other) < 0.6 * n_half
     assert n([-100.0, -100, -100, 100, 100, 100]) == n_full
+
+
+@pytest.mark.parametrize("layers,width,enc", [(4, 128, "none"), (8, 256, "none"), (4, 128, "barf")])
+def test_one_call_grid_iteration_equals_the_call_by_call_sequence(layers, width, enc):
+    """afx_march_train_step_mse / render.march_train_step_mse: the reference's grid iteration (run_nerf_acc.py:284-306) as one library call -
+    the entry points of occupancy.ray_marching(return_packed=True) + render.train_step_packed_mse in the same order - gives the same
+    pixels, gradients and kept count bit for bit; an empty grid skips the step; a too-small workspace grows and the call is repeated."""
+    from nerf_for_angiography_amd.nerf.nerf_helpers_acc import acc_ray_marching
+    from nerf_for_angiography_amd.nerf.occupancy import OccupancyGrid
+    from nerf_for_angiography_amd.render import train_step_packed_mse, march_train_step_mse
+    o, d, tgt = _ref_iteration_problem(1500, seed=17)
+    o, d, tgt = o.to(DEV), d.to(DEV), tgt.to(DEV)
+    aabb = torch.tensor([-100.0, -100, -100, 100, 100, 100], device=DEV)
+    res = 64
+    c = (torch.stack(torch.meshgrid(*[torch.arange(res)] * 3, indexing="ij"), -1).float() + 0.5) / res * 200 - 100
+    grid = OccupancyGrid(roi_aabb=aabb, resolution=res).to(DEV)
+    grid._binary = (c.norm(dim=-1) < 55).to(DEV)
+
+    def model():
+        torch.manual_seed(8)
+        m = make_model(layers, width, pos_enc=enc, precision="f16s8")
+        if enc == "barf":
+            m.update_barf_alpha(2.5, "pts")
+        with torch.no_grad():
+            m.output_linear[0].bias.fill_(-3.0)
+        return m
+
+    m1 = model()
+    with torch.no_grad():
+        ri, ts, te, packed = acc_ray_marching(m1, grid, aabb, o, d, 300, 1400.0, 1600.0, 1e-2, 1e-4, return_packed=True)
+    loss1, pix1 = train_step_packed_mse(m1, o, d, packed, tgt)
+    g1 = torch.cat([p.grad.reshape(-1) for p in m1._hip_params()])
+    m2 = model()
+    m2.engine._ws = None                       # start from the 64 MiB default: the 8x256 case has to grow it and run again
+    loss2, pix2, kept = march_train_step_mse(m2, grid, aabb, o, d, 300, 1400.0, 1600.0, 1e-2, 1e-4, tgt)
+    g2 = torch.cat([p.grad.reshape(-1) for p in m2._hip_params()])
+    assert kept == ri.numel() > 1000
+    assert torch.equal(pix1, pix2) and torch.equal(g1, g2) and float(loss1) == float(loss2)
+    grid._binary = torch.zeros(res, res, res, dtype=torch.bool, device=DEV)
+    m3 = model()
+    assert march_train_step_mse(m3, grid, aabb, o, d, 300, 1400.0, 1600.0, 1e-2, 1e-4, tgt) == (None, None, 0)
+    assert all(p.grad is None for p in m3._hip_params())

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """The reference's grid-march training iteration (nerf/run_nerf_acc.py:284-307) in isolation: 5 625 rays x 300 steps, 4x128 (or `layers width`),
 occupancy grid shaped like a trained vessel tree (a few % of the cells), fused packed step vs the operator sequence.  Prints ms / iteration;
-run under `rocprofv3 --kernel-trace --stats` for the per-kernel split.  usage: grid_iter.py [layers width [iters [ops|fused [fill]]]]"""
+run under `rocprofv3 --kernel-trace --stats` for the per-kernel split.  usage: grid_iter.py [layers width [iters [ops|fused|one [fill]]]]"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 from nerf_for_angiography_amd.model.CPPN import CPPN
-from nerf_for_angiography_amd.render import train_step_packed_mse
+from nerf_for_angiography_amd.render import train_step_packed_mse, march_train_step_mse
 from nerf_for_angiography_amd.engine import sample_rays, RayBatchSampler
 from nerf_for_angiography_amd.nerf.nerf_helpers import get_predictions
 from nerf_for_angiography_amd.nerf.nerf_helpers_acc import acc_ray_marching, acc_render_volume_density
@@ -48,6 +48,12 @@ def it():
     n[0] += 1
     o, d, tgt, _ = batches.draw(n[0]) if batches else sample_rays(tab_o, tab_d, tab_p, tab_w, R, seed=0, stream_id=n[0])
     opt.zero_grad(set_to_none=True)
+    if mode == "one":      # the whole iteration body in one library call
+        _, _, kept = march_train_step_mse(m, grid, aabb, o, d, S, near, far, 1e-2, 1e-4, tgt)
+        tot[0] += kept
+        if kept:
+            opt.step()
+        return
     with torch.no_grad():
         out = acc_ray_marching(m, grid, aabb, o, d, S, near, far, 1e-2, 1e-4, return_packed=(mode == "fused"))
     ri, ts, te = out[:3]
