@@ -71,6 +71,9 @@ struct afx_ctx {
   const float* coef_params = nullptr;   // afx_set_encoding_grad: fp32 flat parameters (W_0 is read from them) ...
   float* d_coef = nullptr;              // ... and where d loss / d fourier coefficients accumulates (null: coefficients are constants)
   std::vector<ProfRec> recs;
+  int64_t* mailbox = nullptr;           // afx_march_train_step_mse: 2 x 4 host-mapped words the offsets kernel posts its totals to (lazily allocated)
+  int64_t* mailbox_dev = nullptr;
+  int64_t mail_seq = 0;
 };
 
 // Optional HIP-event bracket around one kernel launch, on the launch stream (bench.py's roofline leg).
@@ -200,6 +203,7 @@ extern "C" void afx_destroy(afx_ctx* c) {
   for (auto e : c->ev_chain) if (e) (void)hipEventDestroy(e);
   for (auto e : c->ev_wgrad) if (e) (void)hipEventDestroy(e);
   if (c->side) (void)hipStreamDestroy(c->side);
+  if (c->mailbox) (void)hipHostFree(c->mailbox);
   delete c;
 }
 
@@ -1360,11 +1364,41 @@ extern "C" int afx_march_train_step_mse(afx_ctx* c, int prec, const void* prepar
   int64_t* offsets = (int64_t*)(ws + o_offsets);
   int64_t* totals = (int64_t*)(ws + o_totals);
   int rc;
-  if ((rc = afx_march_count(&m, counts, stream))) return rc;
-  if ((rc = afx_ray_offsets(counts, R, offsets, nullptr, totals, stream))) return rc;
+  // The two size read-backs: the offsets kernel posts its totals and a sequence tag to host-mapped memory and the host polls the tag
+  // (AFX_MAILBOX=0: a 16-byte copy + stream synchronisation behind the kernel instead - 27 us per read-back slower, tools/grid_iter.py).
+  static const bool use_mailbox = !(getenv("AFX_MAILBOX") && atoi(getenv("AFX_MAILBOX")) == 0);
+  if (use_mailbox && !c->mailbox) {
+    if (hipHostMalloc((void**)&c->mailbox, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer((void**)&c->mailbox_dev, c->mailbox, 0) != hipSuccess) {
+      if (c->mailbox) (void)hipHostFree(c->mailbox);
+      c->mailbox = c->mailbox_dev = nullptr;
+    } else for (int i = 0; i < 8; ++i) c->mailbox[i] = 0;
+  }
+  const bool mail = use_mailbox && c->mailbox;
   int64_t h[4] = {0, 0, 0, 0};
-  HIPCHK(hipMemcpyAsync(h, totals, 16, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));      // (sizes are data: the candidate count)
+  auto read_totals = [&](const int32_t* cnt, int64_t* offs, int64_t* goffs, int slot) -> int {
+    if (!mail) {
+      if (int r = afx_ray_offsets(cnt, R, offs, goffs, totals + 2 * slot, stream)) return r;
+      HIPCHK(hipMemcpyAsync(h + 2 * slot, totals + 2 * slot, 16, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      return AFX_OK;
+    }
+    const int64_t tag = ++c->mail_seq;
+    hipLaunchKernelGGL(k_ray_offsets, dim3(1), dim3(1024), 0, st, cnt, R, offs, goffs, totals + 2 * slot, (volatile int64_t*)(c->mailbox_dev + 4 * slot), tag);
+    HIPCHK(hipGetLastError());
+    volatile int64_t* mb = c->mailbox + 4 * slot;
+    for (uint64_t spins = 0; mb[2] != tag; ++spins) {
+      if ((spins & 0xfffff) == 0xfffff && hipStreamQuery(st) != hipErrorNotReady) {      // the stream has drained (or failed): one last look
+        HIPCHK(hipStreamSynchronize(st));
+        if (mb[2] != tag) return fail(AFX_E_HIP, "afx_march_train_step_mse: the offsets kernel never posted its totals");
+        break;
+      }
+      __builtin_ia32_pause();
+    }
+    h[2 * slot] = mb[0]; h[2 * slot + 1] = mb[1];
+    return AFX_OK;
+  };
+  if ((rc = afx_march_count(&m, counts, stream))) return rc;
+  if ((rc = read_totals(counts, offsets, nullptr, 0))) return rc;      // (sizes are data: the candidate count)
   const int64_t n = h[0];
   t->n_candidates = n;
   if (n == 0) return AFX_OK;
@@ -1381,9 +1415,7 @@ extern "C" int afx_march_train_step_mse(afx_ctx* c, int prec, const void* prepar
   int32_t* counts2 = (int32_t*)(ws + o_counts2);
   int64_t *off2 = (int64_t*)(ws + o_off2), *goff = (int64_t*)(ws + o_goff);
   if ((rc = afx_march_visibility(raw, 0, ts, te, offsets, R, t->early_stop_eps, t->alpha_thre, keep, counts2, stream))) return rc;
-  if ((rc = afx_ray_offsets(counts2, R, off2, goff, totals + 2, stream))) return rc;
-  HIPCHK(hipMemcpyAsync(h + 2, totals + 2, 16, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));      // (the kept count and the group count)
+  if ((rc = read_totals(counts2, off2, goff, 1))) return rc;      // (the kept count and the group count)
   const int64_t n2 = h[2], ng = h[3];
   t->n_kept = n2; t->n_groups = ng;
   if (n2 == 0) return AFX_OK;            // nothing survived: the reference skips the step (:293)

@@ -293,7 +293,10 @@ __global__ void __launch_bounds__(256) k_march_visibility(const float* raw, int 
 // ray) and the two totals in one place for the host's single read.  One block: R is a batch of rays (5 625 in the reference), and the
 // torch sequence this replaces (zeros, cumsum = 2 rocprim launches, for the groups another 4) was a quarter of the launches of the
 // dispatch-bound grid iteration.
-__global__ void __launch_bounds__(1024) k_ray_offsets(const int32_t* counts, int64_t n_rays, int64_t* offsets, int64_t* group_offsets, int64_t* totals) {
+// `mailbox` (host-mapped, fine-grained memory; afx_march_train_step_mse): the two totals and then `tag`, behind a system-scope fence - the host
+// polls the tag instead of queueing a copy and a stream synchronisation behind the kernel.
+__global__ void __launch_bounds__(1024) k_ray_offsets(const int32_t* counts, int64_t n_rays, int64_t* offsets, int64_t* group_offsets, int64_t* totals,
+                                                       volatile int64_t* mailbox = nullptr, int64_t tag = 0) {
   __shared__ int64_t ps[1024], pg[1024];
   const int t = threadIdx.x;
   const int64_t per = (n_rays + 1023) / 1024, r0 = t * per, r1 = r0 + per < n_rays ? r0 + per : n_rays;
@@ -318,6 +321,11 @@ __global__ void __launch_bounds__(1024) k_ray_offsets(const int32_t* counts, int
     offsets[n_rays] = ps[1023];
     if (group_offsets) group_offsets[n_rays] = pg[1023];
     if (totals) { totals[0] = ps[1023]; totals[1] = pg[1023]; }
+    if (mailbox) {
+      mailbox[0] = ps[1023]; mailbox[1] = pg[1023];
+      __threadfence_system();
+      mailbox[2] = tag;
+    }
   }
 }
 
