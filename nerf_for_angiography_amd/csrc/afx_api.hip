@@ -644,14 +644,21 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
   // the chain kernel of chunk i+1 runs on the caller's stream (one is MFMA/HBM-write heavy, the other HBM-read
   // bound).  Fork/join with events only; the side stream always rejoins the caller's stream before returning.
   int nbuf = 1;
-  if (c->overlap && chunk < tiles && chunk >= 8 && !split) {
+  // AFX_OVERLAP=2 (measurement): also a list that fits one chunk is cut in two, and the split-phase step takes part - the idea being that at the
+  // reference's batch the chain halves are VALU-bound and the weight-gradient kernel HBM-bound.  Measured (tools/ref_iter.py): SLOWER, 1.12 -> 1.21 ms
+  // per 5 625 x 300 iteration at 4x128, 5.32 -> 5.38 ms at 8x256 (two half-size launches of everything); the default stays off.
+  const bool force2 = c->overlap == 2 && tiles >= 16 && !goff;
+  if (c->overlap && (chunk < tiles || force2) && chunk >= 8 && (!split || force2)) {
     if (!c->side) {
       HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
       for (auto& e : c->ev_chain) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
       for (auto& e : c->ev_wgrad) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     nbuf = 2;
-    chunk /= 2;
+    const int64_t one = chunk;
+    chunk = force2 && chunk >= tiles ? (tiles + 1) / 2 : chunk / 2;
+    if (split) chunk = (chunk + ray_tiles - 1) / ray_tiles * ray_tiles;      // whole rays per chunk
+    if (chunk >= tiles || chunk < 1 || fixed + 1024 + (size_t)(2 * chunk) * B.per_tile_bytes > ws_bytes) { nbuf = 1; chunk = one; }      // (two buffers must fit)
   }
   size_t off = head;
   float* partial = (float*)(ws + off); off += rup64((size_t)(N + 2) * kSplits * F * F * 4, 256);
