@@ -115,6 +115,18 @@ def test_context_queries_and_validation_without_gpu():
         rc = lib.afx_hier_train_step_mse(h, _lib.PREC["f16s8"], 4096, C.byref(args), 7, 4096, 4096, 1.0, None, 4096, None)
         assert rc == -2 and b"workspace" in lib.afx_last_error(), (rc, lib.afx_last_error())
     assert lib.afx_hier_train_step_mse(h, _lib.PREC["f16"], 4096, C.byref(args), 7, 4096, 4096, 1.0, None, 4096, None) == -1
+    # the one-call grid iteration and the batched ray draws validate before they touch a device
+    mt = _lib.MarchTrainArgs()
+    assert lib.afx_march_train_step_mse(h, _lib.PREC["f16s8"], 4096, None, None) == -1
+    assert lib.afx_march_train_step_mse(h, _lib.PREC["f16s8"], 4096, C.byref(mt), None) == 0 and mt.n_kept == 0          # zero rays: nothing to do
+    mt.march.n_rays = 8
+    assert lib.afx_march_train_step_mse(h, _lib.PREC["f16s8"], 4096, C.byref(mt), None) == -1 and b"null" in lib.afx_last_error()
+    mt.march.origins = mt.march.dirs = mt.target = mt.pixel = mt.grad_flat = mt.workspace = 4096
+    assert lib.afx_march_train_step_mse(h, _lib.PREC["f16"], 4096, C.byref(mt), None) == -1 and b"F16S8" in lib.afx_last_error()
+    assert lib.afx_sample_batches(4096, 100, 0, 0, 4, 101, 4096, 4096, 1 << 20, None) == -1                                # k > n
+    assert lib.afx_sample_batches(4096, 100, 0, 0, 4, 10, 4096, 4096, 16, None) == -2                                      # workspace
+    assert lib.afx_sample_batches_workspace_bytes(900000, 16) >= 16 * 900000 * 4
+    assert lib.afx_ray_offsets(None, 5, None, None, None, None) == -1
     lib.afx_destroy(h)
 
 
