@@ -418,6 +418,7 @@ __global__ void __launch_bounds__(64 * NW, chain_occ2(F / 32, PHASE) ? 4 : NW / 
   };
 
   constexpr uint32_t MASKB = 2u * NT * NCG * NTH;      // mask bytes per layer (the LDS image, [((l*NT + t)*NCG + cg)*NTH + tid] u16)
+  uint32_t wave_gmax = 0;      // (lane 0) the largest |dL/draw| this wave has merged into a.gmax so far
   for (int tile = a.tile0 + blockIdx.x; tile < a.tile1; tile += gridDim.x) {
     STAMP(7);
     if constexpr (P2) {
@@ -929,8 +930,13 @@ __global__ void __launch_bounds__(64 * NW, chain_occ2(F / 32, PHASE) ? 4 : NW / 
           float gm = fabsf(g[cg]);
 #pragma unroll
           for (int sh = 16; sh >= 1; sh >>= 1) gm = fmaxf(gm, __shfl_xor(gm, sh));
-          // integer max of non-negative float bit patterns: order-independent, so the result is deterministic
-          if (lane == 0 && gm > 0.f) atomicMax(a.gmax, __builtin_bit_cast(uint32_t, gm));
+          // integer max of non-negative float bit patterns: order-independent, so the result is deterministic.  A wave merges only a NEW
+          // maximum of its own (`wave_gmax` lives across the tiles of this workgroup): one atomic per wave and tile to ONE address is 56 000
+          // same-address atomics per launch at the reference's batch (~6 ns each, serialised at the memory side, and vmcnt-counted, so every
+          // wave waits its turn at the next step) - the backward half ran 736 us with real gradients against 366 us with all-zero ones
+          // (where `gm > 0` never fires), the whole of the difference.
+          const uint32_t gbits = __builtin_bit_cast(uint32_t, gm);
+          if (lane == 0 && gbits > wave_gmax) { atomicMax(a.gmax, gbits); wave_gmax = gbits; }
           if constexpr (S8) {
             // 8-bit stash: dZ' = g_hat J with g normalised by its 32-sample group's power of two, |g_hat| <= 1; the group's
             // exponent goes to the weight-gradient kernel as the block scale of the MX matrix instruction

@@ -26,6 +26,13 @@ if os.environ.get("AFX_VARIANT"):
     m._engine = Engine(width, layers, md["pos_enc"], 5 if md["pos_enc"] != "none" else 0, variant=os.environ["AFX_VARIANT"])
 if md["pos_enc"] == "barf":
     m.update_barf_alpha(2.5, "pts")
+# the driver's --out_bias_init (default -5).  NOT cosmetic: with the default bias 0 the 300 samples of a ray absorb everything (pixel = e^-100),
+# every gradient is exactly zero, and the backward half then runs TWICE as fast as on real gradients (round 3 measured this tool in that
+# state until the driver's own rate, 646 it/s against the tool's 890, gave it away) - OBIAS=0 reproduces the degenerate state
+with torch.no_grad():
+    m.output_linear[0].bias.fill_(float(os.environ.get("OBIAS", "-5")))
+if os.environ.get("TARGET") == "const":
+    tab_p = torch.full_like(tab_p, 0.9)
 opt = torch.optim.Adam(m.parameters(), lr=1e-4, fused=os.environ.get("ADAM_FUSED", "1") != "0")      # (one multi-tensor kernel instead of the foreach sequence)
 R, S = 5625, 300
 n = [0]
