@@ -20,7 +20,9 @@ if os.environ.get("PRE"):      # what tools/measure_configs.py does before C3: a
     del mp, specp
 m = CPPN(md).to(dev)
 with torch.no_grad():
-    m.output_linear[0].weight.mul_(4.0); m.output_linear[0].bias.fill_(-5.0)
+    # dense convention: the last interval is 1e10 long, so any sigma(far) > 1e-9 renders the pixel as exactly 0 and every gradient as exactly 0 - a bias of
+    # -26 (sigma = 5e-12) keeps real gradients in the step (OBIAS=-5: the degenerate state this tool measured until the end of round 3)
+    m.output_linear[0].bias.fill_(float(os.environ.get("OBIAS", "-26")))
 m.engine.max_workspace_bytes = 128 << 30
 opt = torch.optim.Adam(m.parameters(), lr=1e-4, fused=True)
 if os.environ.get("WS_FIRST"):
