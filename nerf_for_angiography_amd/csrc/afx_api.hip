@@ -751,7 +751,9 @@ static int run_backward(afx_ctx* c, int prec, ChainArgs a, size_t head, char* ws
     ReduceArgs rd = {};
     rd.partial = partial; rd.partial2 = partial2; rd.n_hidden = N; rd.k0 = c->k0; rd.k0pad = k0ld; rd.n_splits = splits;
     rd.grad = grad_flat; rd.hidden_only = b16 ? 1 : 0; rd.partial_s = partial_s;
-    rd.n_small = kSmallBlocks;      // records; every record is written (possibly with zero rows)
+    // records (every one is written, possibly with zero rows): a block per ~4 groups of a small list, so that a sparse grid iteration (a few hundred
+    // groups) does not write and sum 1 024 records of which most are zeros
+    rd.n_small = (int)std::min<int64_t>(kSmallBlocks, std::max<int64_t>(64, (w.rows / GROUP + 3) / 4));
     rd.gmax = a.gmax; rd.scale_shift = s8 ? AFX_S8_JSHIFT : 0; rd.layer0_mfma = enc16 ? 1 : 0;
     rd.w0 = c->coef_params; rd.d_coef = c->d_coef; rd.coef_cols = a.coef_cols;
     if (!b16) rc = F == 64 ? launch_wgrad_t<64>(c, w, rd, N, ws_st) : (F == 128 ? launch_wgrad_t<128>(c, w, rd, N, ws_st) : launch_wgrad_t<256>(c, w, rd, N, ws_st));
