@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-DEPS = ["afx_api.hip", "afx_kernels_f32.hip", "afx_kernels_bf16.hip", "afx_inst.h", "afx_inst_chain16.hip",
+DEPS = ["afx_api.hip", "afx_kernels_f32.hip", "afx_kernels_bf16.hip", "afx_kernels_grid.hip", "afx_inst.h", "afx_inst_chain16.hip",
         "afx_internal.h", os.path.join("..", "..", "include", "afx.h")]
 VARIANTS = {"": [], "safe": ["-DAFX_SAFE_WAITS"],
             "window": ["-DAFX_STASH_WINDOW"],     # measurement: stash stores into an L2-resident window (no HBM write stream; wrong results)

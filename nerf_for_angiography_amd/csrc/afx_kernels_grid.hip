@@ -257,6 +257,7 @@ __global__ void __launch_bounds__(256) k_march_write(const MarchArgs a, const in
 // (wave-uniform loop of lane broadcasts: the same multiplications in the same order as a sequential march, so the kept set is the same bit for bit).
 __global__ void __launch_bounds__(256) k_march_visibility(const float* raw, int is_alpha, const float* t_starts, const float* t_ends, const int64_t* offsets, int64_t n_rays,
                                                           float early_stop_eps, float alpha_thre, uint8_t* keep, int32_t* counts) {
+  __shared__ float sf[4][64];
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (r >= n_rays) return;
@@ -274,15 +275,26 @@ __global__ void __launch_bounds__(256) k_march_visibility(const float* raw, int 
       }
     }
     const bool thick = i < i1 && !(alpha < alpha_thre);
-    const uint64_t tb = __ballot(thick);
-    const int nn = (int)((i1 - b) < 64 ? (i1 - b) : 64);
+    // The transmittance in front of each of the 64 samples, IN ORDER and branch-free.  A thin (or absent) sample multiplies by exactly 1, so lane j's
+    // p = ((T f_0) f_1) ... f_(j-1) is the sequential march's value bit for bit: every lane runs the same 64 multiplications on factors that come
+    // back from LDS as broadcast reads (all issued up front), with f_k replaced by 1 in the lanes <= k.  Sample j is kept iff it is thick and p has
+    // not fallen below early_stop_eps (T never grows, so the products behind the stop - which a sequential march does not form - cannot bring a
+    // sample back).  Replaces a loop with two branches and a ds_bpermute per sample, on which the kernel was latency-bound.
     bool mine = false;
-    for (int j = 0; j < nn; ++j) {                 // wave-uniform: T is the same in every lane
-      if (T < early_stop_eps) break;
-      if ((tb >> j) & 1ull) {
-        if (j == lane) mine = true;
-        T = __fmul_rn(T, 1.f - __shfl(alpha, j));
-      }
+    if (!(T < early_stop_eps)) {                   // (wave-uniform)
+      const float f = thick ? 1.f - alpha : 1.f;
+      const int w = threadIdx.x >> 6;
+      sf[w][lane] = f;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (one wave: its LDS operations complete in order; the fence is for the compiler)
+      float fk[64];
+#pragma unroll
+      for (int k = 0; k < 64; ++k) fk[k] = sf[w][k];
+      float p = T;
+#pragma unroll
+      for (int k = 0; k < 64; ++k) p = __fmul_rn(p, k < lane ? fk[k] : 1.f);
+      mine = thick && !(p < early_stop_eps);
+      T = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, __fmul_rn(p, f)), 63));
+      asm volatile("" ::: "memory");               // (the next chunk overwrites the factors behind these reads)
     }
     if (i < i1) keep[i] = mine ? 1 : 0;
     c += __popcll(__ballot(mine));

@@ -1,10 +1,9 @@
 #!/usr/bin/env python3
 """What bounds k_march_visibility?  R rays x S candidates each, HIP-event timing of afx_march_visibility alone: S sweep, raw vs ready-made alpha
 (no transcendental work), early stop on / off.  Run under `rocprofv3 --kernel-trace` for the kernel's own time.
-Findings (end of round 3, not resolved): 12.7 / 21 / 38.6 / 86 us for S = 32 / 64 / 128 / 300 - linear in the samples per ray, the same with
-ready-made alphas, without early stop, with the keep[] byte stores removed, and with three different forms of the in-order transmittance
-product (branchy loop + ds_bpermute, 64 x v_mul + v_mov_dpp wave_shr, LDS-broadcast factors + masked multiplies): none of those is what
-bounds it.  5 % of the driver's grid iteration while the grid is full; 7 us once it is sparse."""
+Findings: 12.7 / 21 / 38.6 / 86 us for S = 32 / 64 / 128 / 300 with the original loop (two branches and a ds_bpermute per sample: latency-bound);
+6.6 / 6.6 / 11 / 18 us with the branch-free in-order product on LDS-broadcast factors.  (Three rewrites first "measured" exactly the old time:
+csrc/afx_kernels_grid.hip was missing from build.py's dependency list, so none of them had been compiled.)"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
