@@ -309,20 +309,33 @@ __global__ void __launch_bounds__(256) k_march_visibility(const float* raw, int 
 // polls the tag instead of queueing a copy and a stream synchronisation behind the kernel.
 __global__ void __launch_bounds__(1024) k_ray_offsets(const int32_t* counts, int64_t n_rays, int64_t* offsets, int64_t* group_offsets, int64_t* totals,
                                                        volatile int64_t* mailbox = nullptr, int64_t tag = 0) {
-  __shared__ int64_t ps[1024], pg[1024];
-  const int t = threadIdx.x;
+  __shared__ int64_t ws_[16], wg_[16];      // the 16 waves' totals, then their exclusive prefix
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int64_t per = (n_rays + 1023) / 1024, r0 = t * per, r1 = r0 + per < n_rays ? r0 + per : n_rays;
   int64_t s = 0, g = 0;
   for (int64_t r = r0; r < r1; ++r) { const int64_t c = counts[r]; s += c; g += (c + 31) >> 5; }
-  ps[t] = s; pg[t] = g;
-  __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {      // Hillis-Steele inclusive scan of the 1024 partial sums
-    const int64_t as = t >= d ? ps[t - d] : 0, ag = t >= d ? pg[t - d] : 0;
-    __syncthreads();
-    ps[t] += as; pg[t] += ag;
-    __syncthreads();
+  // inclusive scan inside the wave (6 shuffle steps), the 16 wave totals by one wave, two barriers in all
+  int64_t is = s, ig = g;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int64_t as = __shfl_up(is, d), ag = __shfl_up(ig, d);
+    if (lane >= d) { is += as; ig += ag; }
   }
-  s = ps[t] - s; g = pg[t] - g;             // exclusive
+  if (lane == 63) { ws_[wave] = is; wg_[wave] = ig; }
+  __syncthreads();
+  if (wave == 0) {
+    int64_t a = lane < 16 ? ws_[lane] : 0, b = lane < 16 ? wg_[lane] : 0;
+    const int64_t a0 = a, b0 = b;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+      const int64_t as = __shfl_up(a, d), ag = __shfl_up(b, d);
+      if (lane >= d) { a += as; b += ag; }
+    }
+    if (lane < 16) { ws_[lane] = a - a0; wg_[lane] = b - b0; }      // exclusive
+  }
+  __syncthreads();
+  const int64_t tot_s = ws_[15] + __shfl(is, 63), tot_g = wg_[15] + __shfl(ig, 63);      // (valid in wave 15)
+  s = ws_[wave] + is - s; g = wg_[wave] + ig - g;             // exclusive prefix of this thread's rays
   for (int64_t r = r0; r < r1; ++r) {
     const int64_t c = counts[r];
     offsets[r] = s;
@@ -330,11 +343,11 @@ __global__ void __launch_bounds__(1024) k_ray_offsets(const int32_t* counts, int
     s += c; g += (c + 31) >> 5;
   }
   if (t == 1023) {
-    offsets[n_rays] = ps[1023];
-    if (group_offsets) group_offsets[n_rays] = pg[1023];
-    if (totals) { totals[0] = ps[1023]; totals[1] = pg[1023]; }
+    offsets[n_rays] = tot_s;
+    if (group_offsets) group_offsets[n_rays] = tot_g;
+    if (totals) { totals[0] = tot_s; totals[1] = tot_g; }
     if (mailbox) {
-      mailbox[0] = ps[1023]; mailbox[1] = pg[1023];
+      mailbox[0] = tot_s; mailbox[1] = tot_g;
       __threadfence_system();
       mailbox[2] = tag;
     }
