@@ -583,9 +583,10 @@ static int launch_wgrad8_t(afx_ctx* c, const WgradArgs& w, const ReduceArgs& rd,
   }
   hipLaunchKernelGGL(k_small_from_groups<F>, dim3(rd.n_small), dim3(F, 4), 0, st, w);
   if (w.no_sw) hipLaunchKernelGGL(k_wout_stash8<F>, dim3(rd.n_small), dim3(2 * F), 0, st, w);      // output layer from the stash of H_N (same records)
-  hipLaunchKernelGGL(k_reduce_w<F>, dim3((F * F + 255) / 256, N + 1), dim3(256), 0, st, rd);
-  hipLaunchKernelGGL(k_reduce_b<F>, dim3(1, N + 2), dim3(F), 0, st, rd);
-  hipLaunchKernelGGL(k_reduce_small<F>, dim3((unsigned)((F * rd.k0pad + 2 * F + 1 + 63) / 64)), dim3(64, 4), 0, st, rd);
+  {
+    const int nwx = (F * F + 255) / 256, nw = nwx * (N + 1), nb = N + 2, ns = (int)((F * rd.k0pad + 2 * F + 1 + 63) / 64);
+    hipLaunchKernelGGL(k_reduce_all<F>, dim3((unsigned)(nw + nb + ns)), dim3(256), 0, st, rd, nwx, nw, nb);
+  }
   if (w.coef_cols > 0) hipLaunchKernelGGL(k_reduce_coef<F>, dim3(rd.coef_cols), dim3(F), 0, st, rd);
   HIPCHK(hipGetLastError());
   return AFX_OK;

@@ -1692,11 +1692,10 @@ __global__ void __launch_bounds__(2 * F) k_wout_stash8(const WgradArgs a) {
 // grid = ceil(SS/64) blocks of 64 x 4 threads: 4 record groups per element (fixed-order partial sums, combined in
 // fixed order through LDS), so that the ~5 MB reduction spreads over the whole chip instead of 18 workgroups.
 template <int F>
-__global__ void __launch_bounds__(256) k_reduce_small(const ReduceArgs a) {
+__device__ __forceinline__ void reduce_small_body(const ReduceArgs& a, int bx, int tx, int grp) {
   __shared__ float red[4][64];
   const size_t SS = (size_t)F * a.k0pad + 2 * F + 4;
-  const size_t e = (size_t)blockIdx.x * 64 + threadIdx.x;
-  const int grp = threadIdx.y;
+  const size_t e = (size_t)bx * 64 + tx;
   const bool valid = e <= (size_t)F * a.k0pad + 2 * F;
   float s = 0.f;
   if (valid) {
@@ -1705,11 +1704,11 @@ __global__ void __launch_bounds__(256) k_reduce_small(const ReduceArgs a) {
 #pragma unroll 8
     for (int b = grp * per; b < b1; ++b) s += a.partial_s[(size_t)b * SS + e];
   }
-  red[grp][threadIdx.x] = s;
+  red[grp][tx] = s;
   __syncthreads();
   if (grp != 0 || !valid) return;
   if (a.layer0_mfma && e < (size_t)F * a.k0pad + F) return;      // first layer: reduced by k_reduce_w / k_reduce_b from k_wgrad_bf16's partials
-  s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  s = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
   const size_t wout = (size_t)F * a.k0 + F + (size_t)a.n_hidden * ((size_t)F * F + F);
   size_t dst;
   if (e < (size_t)F * a.k0pad) {
@@ -1719,6 +1718,18 @@ __global__ void __launch_bounds__(256) k_reduce_small(const ReduceArgs a) {
   } else if (e < (size_t)F * a.k0pad + F) dst = (size_t)F * a.k0 + (e - (size_t)F * a.k0pad);
   else dst = wout + (e - (size_t)F * a.k0pad - F);       // F output weights, then the output bias
   a.grad[dst] += s;
+}
+template <int F>
+__global__ void __launch_bounds__(256) k_reduce_small(const ReduceArgs a) { reduce_small_body<F>(a, blockIdx.x, threadIdx.x, threadIdx.y); }
+// The three reductions of the 8-bit-stash path in ONE launch (a training iteration of the reference's batch is a string of launch-latency-sized
+// kernels): blocks [0, nw) sum the hidden layers' weight partials (k_reduce_w's grid, x-major), the next nb the bias partials, the rest the
+// first-/output-layer group records.  Block = 256 threads; each block runs exactly one of the three bodies.
+template <int F>
+__global__ void __launch_bounds__(256) k_reduce_all(const ReduceArgs a, int nwx, int nw, int nb) {
+  const int b = blockIdx.x, t = threadIdx.x;
+  if (b < nw) reduce_w_body<F>(a, b % nwx, b / nwx, t);
+  else if (b < nw + nb) { if (t < F) reduce_b_body<F>(a, b - nw, t); }
+  else reduce_small_body<F>(a, b - nw - nb, t & 63, t >> 6);
 }
 
 // Fourier coefficients' gradient from k_wgrad_bf16's coefficient pass (slot N+1 of `partial`: G[f][c] = sum_n dZ_0[n][f] D[n][c], D =

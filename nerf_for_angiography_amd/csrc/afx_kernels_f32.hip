@@ -674,13 +674,13 @@ __global__ void __launch_bounds__(1024) k_colsum_f32(const WgradArgs a) {
 }
 
 // grad += sum over splits (fixed order).  grid = (ceil(F*F/256), N+1) for weights.
+// (bodies as device functions: k_reduce_all - one launch for the three reductions of the 8-bit-stash path - calls them by block range)
 template <int F>
-__global__ void k_reduce_w(const ReduceArgs a) {
-  const int layer = blockIdx.y;
+__device__ __forceinline__ void reduce_w_body(const ReduceArgs& a, int bx, int layer, int tx) {
   if (a.hidden_only && layer == 0 && !a.layer0_mfma) return;
   const int ncols = layer == 0 ? a.k0pad : F;
   const int ncr = layer == 0 ? a.k0 : F;
-  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int e = bx * 256 + tx;
   if (e >= F * ncols) return;
   const int row = e / ncols, c = e % ncols;
   if (c >= ncr) return;
@@ -692,11 +692,12 @@ __global__ void k_reduce_w(const ReduceArgs a) {
   if (a.gmax) s *= ldexpf(1.f, wgrad_scale_exp(a.gmax) - a.scale_shift);       // f16 mode (hidden layers only reach here): undo Ls, exact
   a.grad[off + (size_t)row * ncr + c] += s;
 }
+template <int F>
+__global__ void k_reduce_w(const ReduceArgs a) { reduce_w_body<F>(a, blockIdx.x, blockIdx.y, threadIdx.x); }
 
 // biases + output layer.  grid = (1, N+2), block = F.
 template <int F>
-__global__ void k_reduce_b(const ReduceArgs a) {
-  const int y = blockIdx.y, f = threadIdx.x;
+__device__ __forceinline__ void reduce_b_body(const ReduceArgs& a, int y, int f) {
   if (a.hidden_only && ((y == 0 && !a.layer0_mfma) || y == a.n_hidden + 1)) return;
   float s = 0.f, sg = 0.f;
 #pragma unroll 8
@@ -715,6 +716,8 @@ __global__ void k_reduce_b(const ReduceArgs a) {
     if (f == 0) a.grad[wout + F] += sg;
   }
 }
+template <int F>
+__global__ void k_reduce_b(const ReduceArgs a) { reduce_b_body<F>(a, blockIdx.y, threadIdx.x); }
 
 #ifndef AFX_TEMPLATES_ONLY      // plain kernels below: defined once, in the host translation unit
 // ---------------------------------------------------------------------------------------
