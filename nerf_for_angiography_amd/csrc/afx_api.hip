@@ -347,14 +347,14 @@ extern "C" int afx_prepare_weights(afx_ctx* c, int prec, const float* params, co
   p.small_off = L.small_off; p.slab0_off = L.slab0_off; p.fwd_off = L.fwd_off; p.bwd_off = L.bwd_off;
   p.slab0_bytes = L.slab0_bytes; p.slabh_bytes = L.slabh_stride; p.small_floats = L.small_floats;
   p.weights = prec == AFX_PREC_F32 ? 1 : 0;
-  hipLaunchKernelGGL(k_prepare_f32, dim3(512), dim3(256), 0, (hipStream_t)stream, p);
-  if (is_bf16(prec)) {
+  if (!is_bf16(prec)) hipLaunchKernelGGL(k_prepare_f32, dim3(512), dim3(256), 0, (hipStream_t)stream, p);
+  else {
     PrepArgs16 q = {};
     q.params = params; q.prepared = (char*)prepared;
     q.F = c->d.width; q.n_hidden = c->d.n_hidden; q.k0 = c->k0; q.nk0 = nk0_of(c); q.parts = prec == AFX_PREC_BF16X3 ? 2 : 1;
     q.slab0_off = L.slab0_off; q.slab0_bytes = L.slab0_bytes; q.fwd_off = L.fwd_off; q.slabh_stride = L.slabh_stride;
     q.bwd_off = L.bwd_off; q.slabt_bytes = L.slabt_bytes; q.lo_off = L.lo_off; q.h16 = is_f16(prec) ? 1 : 0;
-    hipLaunchKernelGGL(k_prepare_bf16, dim3(512), dim3(256), 0, (hipStream_t)stream, q);
+    hipLaunchKernelGGL(k_prepare_both, dim3(1024), dim3(256), 0, (hipStream_t)stream, p, q);
   }
   HIPCHK(hipGetLastError());
   return AFX_OK;

@@ -1770,12 +1770,10 @@ struct PrepArgs16 {
 
 __device__ __forceinline__ unsigned short bf16_rne(float x) { return (unsigned short)(pack2(x, 0.f) & 0xffffu); }
 
-__global__ void k_prepare_bf16(const PrepArgs16 p) {
+__device__ __forceinline__ void prepare_bf16_body(const PrepArgs16& p, int64_t gid, int64_t gsz) {
   const int F = p.F, NT = F / 32, N = p.n_hidden;
   const size_t hidden0 = (size_t)F * p.k0 + F;
   const size_t stride = (size_t)F * F + F;
-  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
   // layer-0 slabs: slab t, element [((q*2 + part)*64 + lane)*8 + j] = W0[32t + (lane&31)][16q + 8(lane>>5) + j]
   {
     unsigned short* s0 = (unsigned short*)(p.prepared + p.slab0_off);
@@ -1821,5 +1819,13 @@ __global__ void k_prepare_bf16(const PrepArgs16 p) {
                               : (unsigned short*)(p.prepared + (part == 0 ? p.fwd_off : p.lo_off) + slab * p.slabt_bytes);
     dst[e] = val;
   }
+}
+__global__ void k_prepare_bf16(const PrepArgs16 p) { prepare_bf16_body(p, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x); }
+// both re-tilings of a 16-bit precision in one launch (the weights are re-tiled after every optimizer step: two launch latencies per training
+// iteration became one): the first half of the grid writes the fp32 `small` section, the second half the 16-bit slabs
+__global__ void k_prepare_both(const PrepArgs p, const PrepArgs16 q) {
+  const int half = gridDim.x / 2;
+  if ((int)blockIdx.x < half) prepare_f32_body(p, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)half * blockDim.x);
+  else prepare_bf16_body(q, (int64_t)(blockIdx.x - half) * blockDim.x + threadIdx.x, (int64_t)half * blockDim.x);
 }
 #endif  // AFX_TEMPLATES_ONLY

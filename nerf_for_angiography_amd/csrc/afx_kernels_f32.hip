@@ -731,12 +731,10 @@ struct PrepArgs {
   uint32_t small_off, slab0_off, fwd_off, bwd_off, slab0_bytes, slabh_bytes, small_floats;
 };
 
-__global__ void k_prepare_f32(const PrepArgs p) {
+__device__ __forceinline__ void prepare_f32_body(const PrepArgs& p, int64_t gid, int64_t gsz) {      // (grid-stride over gsz threads)
   const int F = p.F, NT = F / 32, N = p.n_hidden;
   const size_t hidden0 = (size_t)F * p.k0 + F;
   const size_t stride = (size_t)F * F + F;
-  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
   // small: bias_perm[(l*2+h)*NT+t][16] | wout_perm[(h*NT+t)][16] | bout,0,0,0 | aux
   float* sm = (float*)(p.prepared + p.small_off);
   for (int64_t i = gid; i < p.small_floats; i += gsz) {
@@ -796,6 +794,7 @@ __global__ void k_prepare_f32(const PrepArgs p) {
     (isb ? bw : fw)[ii] = isb ? W[(size_t)k * F + r] : W[(size_t)r * F + k];
   }
 }
+__global__ void k_prepare_f32(const PrepArgs p) { prepare_f32_body(p, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x); }
 
 // ---------------------------------------------------------------------------------------
 // Small per-ray kernels.
