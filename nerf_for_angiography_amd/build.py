@@ -15,6 +15,7 @@ DEPS = ["afx_api.hip", "afx_kernels_f32.hip", "afx_kernels_bf16.hip", "afx_kerne
         "afx_internal.h", os.path.join("..", "..", "include", "afx.h")]
 VARIANTS = {"": [], "safe": ["-DAFX_SAFE_WAITS"],
             "window": ["-DAFX_STASH_WINDOW"],     # measurement: stash stores into an L2-resident window (no HBM write stream; wrong results)
+            "nogmax": ["-DAFX_NO_GMAX_ATOMIC"],      # measurement: the backward kernels without the max|g| atomics (wrong gradients; what do the remaining atomics cost?)
             "p2one": ["-DAFX_P2_OCC2=0"],      # A/B: the backward half of the split step with ONE workgroup per CU at widths <= 128
             "h6": ["-DAFX_H6=1"],      # the 6-bit (bf6 + block scales) H stash: 12.5 % fewer stash bytes, no faster; tests/ compare it with the default
             "h6c": ["-DAFX_H6=1", "-DAFX_H6_CONST"],  # measurement: ... without the scale computation (scale 1; gradients wrong when H leaves [1/16, 28])

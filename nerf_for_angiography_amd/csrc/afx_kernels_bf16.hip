@@ -354,6 +354,11 @@ __global__ void __launch_bounds__(64 * NW, chain_occ2(F / 32, PHASE) ? 4 : NW / 
   const float* bias_perm = sm;
   const float* wout_perm = sm + (N + 1) * F;
   const float* aux = sm + (N + 2) * F + 4;
+  // the workgroup's largest |dL/draw| (f16 backward kernels), merged into a.gmax once, at the end: a word of the 256 spare bytes behind the
+  // mask image (backward kernels only; the per-group optical depths use the first 32) - NOT a static __shared__ variable: the kernels ask for the
+  // full 160 KiB as dynamic LDS, and static bytes on top of that make hipFuncSetAttribute refuse
+  uint32_t* const wg_gmax_p = (uint32_t*)(slot0 + RING * (size_t)SLOT + (size_t)(N + 1) * MW * NCG * NTH * 4 + 128);
+  if constexpr (BWD) { if (tid == 0) *wg_gmax_p = 0; }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the first PD steps' slabs; every later step counts (below)
   __syncthreads();
 
@@ -418,7 +423,7 @@ __global__ void __launch_bounds__(64 * NW, chain_occ2(F / 32, PHASE) ? 4 : NW / 
   };
 
   constexpr uint32_t MASKB = 2u * NT * NCG * NTH;      // mask bytes per layer (the LDS image, [((l*NT + t)*NCG + cg)*NTH + tid] u16)
-  uint32_t wave_gmax = 0;      // (lane 0) the largest |dL/draw| this wave has merged into a.gmax so far
+  uint32_t wave_gmax = 0;      // (lane 0) the largest |dL/draw| this wave has merged into wg_gmax so far
   for (int tile = a.tile0 + blockIdx.x; tile < a.tile1; tile += gridDim.x) {
     STAMP(7);
     if constexpr (P2) {
@@ -930,13 +935,16 @@ __global__ void __launch_bounds__(64 * NW, chain_occ2(F / 32, PHASE) ? 4 : NW / 
           float gm = fabsf(g[cg]);
 #pragma unroll
           for (int sh = 16; sh >= 1; sh >>= 1) gm = fmaxf(gm, __shfl_xor(gm, sh));
-          // integer max of non-negative float bit patterns: order-independent, so the result is deterministic.  A wave merges only a NEW
-          // maximum of its own (`wave_gmax` lives across the tiles of this workgroup): one atomic per wave and tile to ONE address is 56 000
+          // integer max of non-negative float bit patterns: order-independent, so the result is deterministic.  Nothing reads a.gmax before the
+          // launch ends, so a wave merges a NEW maximum of its own (`wave_gmax` lives across the tiles of this workgroup) into an LDS word and the
+          // workgroup issues ONE global atomic when it has run out of tiles.  One global atomic per wave and tile to ONE address was 56 000
           // same-address atomics per launch at the reference's batch (~6 ns each, serialised at the memory side, and vmcnt-counted, so every
-          // wave waits its turn at the next step) - the backward half ran 736 us with real gradients against 366 us with all-zero ones
-          // (where `gm > 0` never fires), the whole of the difference.
+          // wave waited its turn at the next step): the backward half ran 736 us with real gradients against 366 us with all-zero ones (where
+          // `gm > 0` never fires); per-wave new maxima alone still cost 42 us of a 1.18 ms iteration at 4x128, 71 us of 0.66 ms at 4x64.
           const uint32_t gbits = __builtin_bit_cast(uint32_t, gm);
-          if (lane == 0 && gbits > wave_gmax) { atomicMax(a.gmax, gbits); wave_gmax = gbits; }
+#ifndef AFX_NO_GMAX_ATOMIC      // (measurement build --variant=nogmax: wrong weight-gradient scale, timing only)
+          if (lane == 0 && gbits > wave_gmax) { atomicMax(wg_gmax_p, gbits); wave_gmax = gbits; }
+#endif
           if constexpr (S8) {
             // 8-bit stash: dZ' = g_hat J with g normalised by its 32-sample group's power of two, |g_hat| <= 1; the group's
             // exponent goes to the weight-gradient kernel as the block scale of the MX matrix instruction
@@ -1106,6 +1114,10 @@ __global__ void __launch_bounds__(64 * NW, chain_occ2(F / 32, PHASE) ? 4 : NW / 
         for (int t = 0; t < NT; ++t) stash_dz_tile(0, t);
       }
     }
+  }
+  if constexpr (BWD && H16 && !P1) {      // every wave has run out of tiles: the workgroup's one merge into the chunk-wide max |g|
+    __syncthreads();
+    if (tid == 0 && *wg_gmax_p) atomicMax(a.gmax, *wg_gmax_p);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef AFX_STAMP
